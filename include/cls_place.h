@@ -1,0 +1,223 @@
+/*
+ * cls_place.h -- C-ABI of the MI355X placement engine (libclsplace.so).
+ *
+ * Drop-in boundary for ONE path of LepistaBioinformatics/classeq2: the
+ * `core::use_cases::place_sequences` use-case.  The reference has no FFI of
+ * its own; the seam a maintainer binds is the pure function
+ *
+ *     place_sequence(header, sequence, &Tree, Option<i32>, Option<f64>,
+ *                    Option<bool>) -> Result<PlacementStatus, MappedErrors>
+ *     (core/src/use_cases/place_sequences/place_sequence.rs:42-50)
+ *
+ * called once per query by the batch driver
+ * (core/src/use_cases/place_sequences/mod.rs:123-159).  The entry points
+ * below replace that call for a whole batch; everything around it (FASTA
+ * reader, annotations, YAML/JSONL writer) can stay in the Rust caller, see
+ * INTEGRATION.md for the Rust `extern "C"` shim.
+ *
+ * Plain pointers and sizes only; no C++ or torch types; nothing unwinds
+ * across this boundary.  All functions return 0 on success, a negative
+ * CLS_E_* code otherwise; cls_last_error() gives the thread-local message.
+ */
+#ifndef CLS_PLACE_H
+#define CLS_PLACE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CLS_ABI_VERSION 1u
+
+/* ---- error codes ------------------------------------------------------- */
+#define CLS_OK 0
+#define CLS_E_INVALID_ARG (-1)   /* null pointer, bad sizes, bad abi_version     */
+#define CLS_E_BAD_TREE (-2)      /* node table is not a tree rooted at row 0     */
+#define CLS_E_BAD_DB (-3)        /* k-mer map inconsistent / unsupported shape   */
+#define CLS_E_NO_DEVICE (-4)     /* no HIP device / HIP extension unusable       */
+#define CLS_E_HIP (-5)           /* a HIP runtime call failed                    */
+#define CLS_E_NOMEM (-6)
+#define CLS_E_INTERNAL (-7)
+
+/* ---- tree: Clade (core/src/domain/dtos/clade.rs:18-38) ------------------ */
+/* NodeType, clade.rs:5-16.  LEAF-ness is decided by `kind` only
+ * (clade.rs:166-172), never by the absence of children. */
+enum { CLS_KIND_ROOT = 0, CLS_KIND_NODE = 1, CLS_KIND_LEAF = 2 };
+
+#define CLS_NO_PARENT UINT64_MAX
+
+/* One row per clade.  Row 0 is `tree.root`; the children of a row occupy
+ * `n_children` consecutive rows starting at `first_child`, in the order of
+ * `Clade.children`.  `id` is the clade's (arbitrary, non-dense) u64 id. */
+typedef struct cls_node {
+    uint64_t id;
+    uint64_t parent;       /* Clade.parent or CLS_NO_PARENT (informational)      */
+    uint32_t first_child;  /* row of the first child (ignored if n_children==0)  */
+    uint32_t n_children;
+    uint8_t kind;          /* CLS_KIND_*                                         */
+    uint8_t has_children;  /* 0: `children: None`; 1: `Some(vec)` (maybe empty)  */
+    uint8_t pad_[6];
+} cls_node;                /* 32 bytes */
+
+/* ---- k-mer index: KmersMap (core/src/domain/dtos/kmers_map.rs:77-87) ---- */
+/* Borrowed flat view of
+ *   KmersMap{ k_size, m_size, map: HashMap<MinimizerKey, MinimizerValue> }
+ *   MinimizerValue(HashMap<u64 /+kmer hash+/, HashSet<u64 /+node ids+/>>)
+ * as two nested CSR levels.  Bucket b holds k-mers
+ * [bucket_kmer_off[b], bucket_kmer_off[b+1]); k-mer j holds node ids
+ * node_ids[kmer_node_off[j] .. kmer_node_off[j+1]) in any order. */
+typedef struct cls_db_desc {
+    uint32_t abi_version;  /* CLS_ABI_VERSION */
+    uint32_t n_nodes;
+    const cls_node* nodes;
+    uint64_t k_size;       /* kSize */
+    uint64_t m_size;       /* mSize */
+    uint64_t n_buckets;
+    const uint64_t* bucket_key;       /* [n_buckets]   MinimizerKey.0            */
+    const uint64_t* bucket_kmer_off;  /* [n_buckets+1]                           */
+    uint64_t n_kmers;
+    const uint64_t* kmer_hash;        /* [n_kmers]     murmur3_x64_128(kmer,0).0 */
+    const uint64_t* kmer_node_off;    /* [n_kmers+1]                             */
+    const uint64_t* node_ids;         /* [kmer_node_off[n_kmers]] clade ids      */
+} cls_db_desc;
+
+/* ---- per-call parameters: the three Option<> arguments ------------------ */
+#define CLS_HAS_MAX_ITERATIONS 1u      /* Some(max_iterations); else 1000        */
+#define CLS_HAS_MIN_MATCH_COVERAGE 2u  /* Some(min_match_coverage); else 0.7     */
+#define CLS_HAS_REMOVE_INTERSECTION 4u /* Some(remove_intersection); else false  */
+
+typedef struct cls_params {
+    uint32_t flags;             /* CLS_HAS_* bits                                */
+    int32_t max_iterations;     /* place_sequence.rs:65                          */
+    double min_match_coverage;  /* clamped to [0,1], place_sequence.rs:67-75     */
+    uint8_t remove_intersection;/* place_sequence.rs:64                          */
+    uint8_t pad_[7];
+} cls_params;                   /* NULL == all None */
+
+/* ---- result: PlacementStatus / MappedErrors as a fixed record ----------- */
+/* One per query, in input order.  The caller rebuilds
+ * Result<PlacementStatus, MappedErrors> from it:
+ *
+ * status                         reference outcome (place_sequence.rs)
+ * CLS_UNCLASSIFIABLE_NO_MATCH    Ok(Unclassifiable("Query sequence {header:?} may not be related to the phylogeny")) :130-139
+ * CLS_UNCLASSIFIABLE_NO_ROOT     Ok(Unclassifiable("Query sequence has no overlapping kmers with the reference tree")) :156-164
+ * CLS_UNCLASSIFIABLE_COVERAGE    Ok(Unclassifiable("Insufficient kmers coverage: {one}")) :247-254   (one = coverage)
+ * CLS_UNCLASSIFIABLE_LEVEL1      Ok(Unclassifiable("Tree introspection not possible. ...")) :446-453
+ * CLS_IDENTITY_FOUND             Ok(IdentityFound(AdherenceTest{clade=clade_id, one, rest})) update_introspection_node.rs:45-85
+ * CLS_MAX_RESOLUTION             Ok(MaxResolutionReached(clade_id, "LCA Accepted")) :461-464
+ * CLS_INCONCLUSIVE               Ok(Inconclusive(.., "Multiple proposals")) :584-598 (set-theoretically
+ *                                unreachable; one = number of tied proposals, clade_id = parent)
+ * CLS_ERR_TOO_FEW_KMERS          Err("The sequence does not contain enough kmers.", UCPLACE0005) :98-102
+ * CLS_ERR_MAX_ITER               Err("The maximum number of iterations has been reached.", UCPLACE0010) :295-301
+ * CLS_ERR_ROOT_NO_CHILDREN       Err("The root node does not have children. This is unexpected.") :199-206
+ * CLS_ERR_INVALID_BASE           the reference panics (kmers_map.rs:440); reported per read instead
+ * CLS_ERR_READ_TOO_LONG          read exceeds the engine's per-read k-mer capacity (cls_db_info.max_read_kmers)
+ */
+enum {
+    CLS_UNCLASSIFIABLE_NO_MATCH = 0,
+    CLS_UNCLASSIFIABLE_NO_ROOT = 1,
+    CLS_UNCLASSIFIABLE_COVERAGE = 2,
+    CLS_UNCLASSIFIABLE_LEVEL1 = 3,
+    CLS_IDENTITY_FOUND = 4,
+    CLS_MAX_RESOLUTION = 5,
+    CLS_INCONCLUSIVE = 6,
+    CLS_ERR_TOO_FEW_KMERS = 7,
+    CLS_ERR_MAX_ITER = 8,
+    CLS_ERR_ROOT_NO_CHILDREN = 9,
+    CLS_ERR_INVALID_BASE = 10,
+    CLS_ERR_READ_TOO_LONG = 11
+};
+
+typedef struct cls_placement {
+    uint8_t status;     /* CLS_* above                                           */
+    uint8_t pad_[3];
+    int32_t one;        /* AdherenceTest.one  (adherence_test.rs:12)             */
+    int32_t rest;       /* AdherenceTest.rest (adherence_test.rs:15)             */
+    uint32_t levels;    /* introspection levels entered (`iteration`, :280)      */
+    uint64_t clade_id;  /* Clade.id of the placement                             */
+} cls_placement;        /* 24 bytes */
+
+/* Optional per-query counters (the tracing span fields
+ * place_sequence.rs:30-41); used by parity tests and by the roofline
+ * accounting of bench.py. */
+typedef struct cls_query_stats {
+    uint32_t n_query_kmers;    /* query.kmers.count       = 2(L-k+1)             */
+    uint32_t n_matched;        /* query.kmers.treeMatches = |M|                  */
+    uint32_t n_with_root;      /* subject.kmers.queryMatches = |M_root|          */
+    uint32_t pad_;
+    uint64_t leaf_postings;    /* sum over M of |{LEAF-kind ids in nodes(h)}|    */
+} cls_query_stats;             /* 24 bytes */
+
+typedef struct cls_db cls_db;  /* opaque, immutable after create (Send + Sync)   */
+
+typedef struct cls_db_info {
+    uint32_t n_nodes;
+    uint32_t max_depth;        /* levels below the root                          */
+    uint32_t max_nonleaf_arity;
+    uint32_t k_size;
+    uint32_t m_size;
+    uint32_t n_buckets;
+    uint64_t n_kmers;
+    uint64_t n_closed_kmers;   /* node-set closed under `parent` (tip-compressed)*/
+    uint64_t table_slots;
+    uint64_t postings_words;
+    uint64_t hbm_bytes;        /* device bytes held by the handle                */
+    uint32_t max_read_kmers;   /* per-read k-mer capacity of the kernels         */
+    int32_t device;
+} cls_db_info;
+
+/* Number of usable HIP devices (0 if none). */
+int cls_device_count(void);
+
+/* Validate + re-encode + upload the index to `device` (-1: current device).
+ * The views in `d` are only borrowed for the duration of the call.
+ * Replaces nothing in the reference (it keeps the Tree in host hash maps,
+ * ports/lib/src/functions/load_database.rs:9-53); called once after it. */
+int cls_db_create(const cls_db_desc* d, int device, cls_db** out);
+void cls_db_destroy(cls_db* db);
+int cls_db_info_get(const cls_db* db, cls_db_info* info);
+
+/* Place `n` queries.  `bases` holds the concatenated sequences exactly as
+ * `SequenceBody` holds them when place_sequence receives them (after the
+ * FASTA stage, sequence.rs:47-56), `offsets[n+1]` their byte ranges.
+ * Host pointers; synchronous; `out[n]` caller-allocated, input order.
+ * Re-entrant: each call uses its own HIP stream.
+ * Replaces: the per-query place_sequence() call, mod.rs:151-159. */
+int cls_place_batch(cls_db* db, const char* bases, const uint64_t* offsets, uint32_t n,
+                    const cls_params* params, cls_placement* out);
+
+/* Same, with every buffer already resident in the HBM of the handle's
+ * device; asynchronous on `hip_stream` (a hipStream_t, NULL = default
+ * stream).  `d_stats` may be NULL.  This is the entry bench.py times. */
+int cls_place_batch_device(cls_db* db, const void* d_bases, const void* d_offsets, uint32_t n,
+                           const cls_params* params, void* d_out, void* d_stats, void* hip_stream);
+
+/* Host-buffer variant that also returns the per-query counters. */
+int cls_place_batch_stats(cls_db* db, const char* bases, const uint64_t* offsets, uint32_t n,
+                          const cls_params* params, cls_placement* out, cls_query_stats* stats);
+
+/* ---- FASTA input stage (file_or_stdin.rs:76-116, sequence.rs:47-56) ------ */
+typedef struct cls_fasta {
+    uint32_t n;               /* records                                        */
+    uint32_t truncated;       /* 1: stopped at "unexpected sequence without header" (error ignored by the caller, mod.rs:119) */
+    char* headers;            /* concatenated header bytes                      */
+    uint64_t* header_off;     /* [n+1]                                          */
+    char* bases;              /* concatenated filtered (upper-case ACGT) bases  */
+    uint64_t* base_off;       /* [n+1]                                          */
+} cls_fasta;
+
+int cls_fasta_parse(const char* text, size_t len, cls_fasta* out);
+void cls_fasta_free(cls_fasta* f);
+
+/* Thread-local message of the last failing call on this thread ("" if none). */
+const char* cls_last_error(void);
+
+/* "classeq2_amd <version> gfx950 abi<N>" */
+const char* cls_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CLS_PLACE_H */
