@@ -1,0 +1,318 @@
+// C-ABI of libclsplace.so (include/cls_place.h): handle management, upload,
+// the host-buffer and device-buffer batch entry points.  Nothing unwinds across
+// the boundary; every failure leaves a thread-local message for cls_last_error().
+#include <hip/hip_runtime.h>
+#include <string.h>
+
+#include <algorithm>
+#include <mutex>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "cls_db.h"
+#include "cls_device.h"
+#include "cls_kernels.h"
+#include "cls_place.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+
+#define CLS_HIP(expr)                                                                       \
+    do {                                                                                    \
+        hipError_t e_ = (expr);                                                             \
+        if (e_ != hipSuccess) return fail(CLS_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+struct Workspace {
+    uint32_t* ptr = nullptr;
+    uint64_t words = 0;
+    hipEvent_t done = nullptr;
+    bool busy = false;
+};
+
+cls::PlaceParams resolve(const cls_params* p) {
+    // place_sequence.rs:64-75
+    cls::PlaceParams r;
+    r.max_iterations = (p && (p->flags & CLS_HAS_MAX_ITERATIONS)) ? p->max_iterations : 1000;
+    r.remove_intersection = (p && (p->flags & CLS_HAS_REMOVE_INTERSECTION)) ? (p->remove_intersection != 0) : 0;
+    double c = 0.7;
+    if (p && (p->flags & CLS_HAS_MIN_MATCH_COVERAGE)) {
+        c = p->min_match_coverage;
+        if (c > 1.0) c = 1.0; else if (c < 0.0) c = 0.0;
+    }
+    r.min_match_coverage = c;
+    return r;
+}
+
+}  // namespace
+
+struct cls_db {
+    int device = 0;
+    int n_cu = 0;
+    cls::DbDev dev{};
+    cls_db_info info{};
+    void* d_nodes = nullptr;
+    void* d_table = nullptr;
+    void* d_postings = nullptr;
+    void* d_bucket_key = nullptr;
+    std::mutex ws_mu;
+    std::vector<Workspace> ws;  // child-counter workspaces (polytomy trees only)
+};
+
+extern "C" const char* cls_last_error(void) { return g_err.c_str(); }
+
+extern "C" const char* cls_version(void) { return "classeq2_amd 0.1.0 gfx950 abi1"; }
+
+extern "C" int cls_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+extern "C" void cls_db_destroy(cls_db* db) {
+    if (!db) return;
+    int prev = 0;
+    bool have_prev = hipGetDevice(&prev) == hipSuccess;
+    (void)hipSetDevice(db->device);
+    for (auto& w : db->ws) {
+        if (w.done) { (void)hipEventSynchronize(w.done); (void)hipEventDestroy(w.done); }
+        if (w.ptr) (void)hipFree(w.ptr);
+    }
+    if (db->d_nodes) (void)hipFree(db->d_nodes);
+    if (db->d_table) (void)hipFree(db->d_table);
+    if (db->d_postings) (void)hipFree(db->d_postings);
+    if (db->d_bucket_key) (void)hipFree(db->d_bucket_key);
+    if (have_prev) (void)hipSetDevice(prev);
+    delete db;
+}
+
+extern "C" int cls_db_create(const cls_db_desc* d, int device, cls_db** out) {
+    if (!out) return fail(CLS_E_INVALID_ARG, "cls_db_create: out is null");
+    *out = nullptr;
+    try {
+        cls::EncodedDb E;
+        std::string err;
+        int rc = cls::encode_db(d, E, err);
+        if (rc != CLS_OK) return fail(rc, "cls_db_create: " + err);
+        if (E.postings.size() >= (1ULL << 32)) return fail(CLS_E_BAD_DB, "cls_db_create: postings exceed 2^32 words");
+        int n_dev = 0;
+        if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev == 0)
+            return fail(CLS_E_NO_DEVICE, "cls_db_create: no HIP device is visible (the placement path has no CPU fallback)");
+        if (device < 0) CLS_HIP(hipGetDevice(&device));
+        if (device >= n_dev) return fail(CLS_E_INVALID_ARG, "cls_db_create: device ordinal out of range");
+        CLS_HIP(hipSetDevice(device));
+        hipDeviceProp_t prop;
+        CLS_HIP(hipGetDeviceProperties(&prop, device));
+        cls_db* db = new cls_db();
+        db->device = device;
+        db->n_cu = prop.multiProcessorCount;
+        auto up = [&](void** dst, const void* src, size_t bytes) -> hipError_t {
+            hipError_t e = hipMalloc(dst, bytes ? bytes : 16);
+            if (e != hipSuccess) return e;
+            return bytes ? hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice) : hipSuccess;
+        };
+        hipError_t e;
+        if ((e = up(&db->d_nodes, E.nodes.data(), E.nodes.size() * sizeof(cls::DNode))) != hipSuccess ||
+            (e = up(&db->d_table, E.table.data(), E.table.size() * sizeof(cls::Slot))) != hipSuccess ||
+            (e = up(&db->d_postings, E.postings.data(), E.postings.size() * 4)) != hipSuccess ||
+            (e = up(&db->d_bucket_key, E.bucket_key.data(), E.bucket_key.size() * 8)) != hipSuccess) {
+            cls_db_destroy(db);
+            return fail(e == hipErrorOutOfMemory ? CLS_E_NOMEM : CLS_E_HIP, std::string("cls_db_create: upload failed: ") + hipGetErrorString(e));
+        }
+        cls::DbDev& v = db->dev;
+        v.nodes = (const cls::DNode*)db->d_nodes;
+        v.table = (const cls::Slot*)db->d_table;
+        v.postings = (const uint32_t*)db->d_postings;
+        v.bucket_key = (const uint64_t*)db->d_bucket_key;
+        v.table_mask = E.table.size() - 1;
+        v.n_nodes = (uint32_t)E.nodes.size();
+        v.n_buckets = (uint32_t)E.bucket_key.size();
+        v.k = E.k;
+        v.m_eff = E.m_eff;
+        v.max_nonleaf_arity = E.max_nonleaf_arity;
+        cls_db_info& i = db->info;
+        i.n_nodes = v.n_nodes;
+        i.max_depth = E.max_depth;
+        i.max_nonleaf_arity = E.max_nonleaf_arity;
+        i.k_size = E.k;
+        i.m_size = E.m;
+        i.n_buckets = (uint32_t)d->n_buckets;
+        i.n_kmers = E.n_kmers;
+        i.n_closed_kmers = E.n_closed;
+        i.table_slots = E.table.size();
+        i.postings_words = E.postings.size();
+        i.hbm_bytes = E.nodes.size() * sizeof(cls::DNode) + E.table.size() * sizeof(cls::Slot) + E.postings.size() * 4 + E.bucket_key.size() * 8;
+        i.max_read_kmers = cls::MAX_READ_KMERS;
+        i.device = device;
+        *out = db;
+        return CLS_OK;
+    } catch (const std::bad_alloc&) {
+        return fail(CLS_E_NOMEM, "cls_db_create: out of host memory");
+    } catch (const std::exception& ex) {
+        return fail(CLS_E_INTERNAL, std::string("cls_db_create: ") + ex.what());
+    } catch (...) {
+        return fail(CLS_E_INTERNAL, "cls_db_create: unknown exception");
+    }
+}
+
+extern "C" int cls_db_validate(const cls_db_desc* d) {
+    try {
+        cls::EncodedDb E;
+        std::string err;
+        int rc = cls::encode_db(d, E, err);
+        if (rc != CLS_OK) return fail(rc, "cls_db_validate: " + err);
+        if (E.postings.size() >= (1ULL << 32)) return fail(CLS_E_BAD_DB, "cls_db_validate: postings exceed 2^32 words");
+        return CLS_OK;
+    } catch (const std::bad_alloc&) {
+        return fail(CLS_E_NOMEM, "cls_db_validate: out of host memory");
+    } catch (...) {
+        return fail(CLS_E_INTERNAL, "cls_db_validate: unknown exception");
+    }
+}
+
+extern "C" int cls_db_info_get(const cls_db* db, cls_db_info* info) {
+    if (!db || !info) return fail(CLS_E_INVALID_ARG, "cls_db_info_get: null argument");
+    *info = db->info;
+    return CLS_OK;
+}
+
+// Take (or grow) a child-counter workspace whose previous user has finished.
+static int acquire_ws(cls_db* db, uint64_t words, size_t* slot) {
+    std::lock_guard<std::mutex> g(db->ws_mu);
+    for (size_t i = 0; i < db->ws.size(); ++i) {
+        Workspace& w = db->ws[i];
+        if (w.busy && hipEventQuery(w.done) == hipSuccess) w.busy = false;
+        if (!w.busy && w.words >= words) { w.busy = true; *slot = i; return CLS_OK; }
+    }
+    Workspace w;
+    if (hipMalloc((void**)&w.ptr, words * 4) != hipSuccess) return fail(CLS_E_NOMEM, "child-counter workspace allocation failed");
+    if (hipEventCreateWithFlags(&w.done, hipEventDisableTiming) != hipSuccess) { (void)hipFree(w.ptr); return fail(CLS_E_HIP, "hipEventCreate failed"); }
+    w.words = words;
+    w.busy = true;
+    db->ws.push_back(w);
+    *slot = db->ws.size() - 1;
+    return CLS_OK;
+}
+
+extern "C" int cls_place_batch_device(cls_db* db, const void* d_bases, const void* d_offsets, uint32_t n,
+                                      const cls_params* params, void* d_out, void* d_stats, void* hip_stream) {
+    if (!db) return fail(CLS_E_INVALID_ARG, "cls_place_batch_device: null handle");
+    if (n == 0) return CLS_OK;
+    if (!d_offsets || !d_out) return fail(CLS_E_INVALID_ARG, "cls_place_batch_device: null buffer");
+    try {
+        hipStream_t stream = (hipStream_t)hip_stream;
+        const cls::PlaceParams prm = resolve(params);
+        const uint32_t grid = cls::place_grid_blocks(n, (uint32_t)db->n_cu, db->dev);
+        const uint64_t ws_words = cls::place_ws_words(db->dev, grid);
+        uint32_t* ws_ptr = nullptr;
+        size_t slot = 0;
+        if (ws_words) {
+            int rc = acquire_ws(db, ws_words, &slot);
+            if (rc != CLS_OK) return rc;
+            ws_ptr = db->ws[slot].ptr;
+        }
+        hipError_t e = cls::launch_place(db->dev, prm, (const uint8_t*)d_bases, (const uint64_t*)d_offsets, n,
+                                         (cls_placement*)d_out, (cls_query_stats*)d_stats, ws_ptr, grid, stream);
+        if (ws_words) {
+            std::lock_guard<std::mutex> g(db->ws_mu);
+            if (hipEventRecord(db->ws[slot].done, stream) != hipSuccess) db->ws[slot].busy = false;
+        }
+        if (e != hipSuccess) return fail(CLS_E_HIP, std::string("kernel launch failed: ") + hipGetErrorString(e));
+        return CLS_OK;
+    } catch (...) {
+        return fail(CLS_E_INTERNAL, "cls_place_batch_device: unknown exception");
+    }
+}
+
+static int place_host(cls_db* db, const char* bases, const uint64_t* offsets, uint32_t n, const cls_params* params,
+                      cls_placement* out, cls_query_stats* stats) {
+    if (!db) return fail(CLS_E_INVALID_ARG, "cls_place_batch: null handle");
+    if (n == 0) return CLS_OK;
+    if (!offsets || !out || (!bases && offsets[n] != offsets[0])) return fail(CLS_E_INVALID_ARG, "cls_place_batch: null buffer");
+    for (uint32_t i = 0; i < n; ++i)
+        if (offsets[i] > offsets[i + 1]) return fail(CLS_E_INVALID_ARG, "cls_place_batch: offsets not monotone");
+    int prev = 0;
+    CLS_HIP(hipGetDevice(&prev));
+    CLS_HIP(hipSetDevice(db->device));
+    hipStream_t stream = nullptr;
+    void *d_bases = nullptr, *d_off = nullptr, *d_out = nullptr, *d_stats = nullptr;
+    int rc = CLS_OK;
+    auto cleanup = [&]() {
+        if (d_bases) (void)hipFree(d_bases);
+        if (d_off) (void)hipFree(d_off);
+        if (d_out) (void)hipFree(d_out);
+        if (d_stats) (void)hipFree(d_stats);
+        if (stream) (void)hipStreamDestroy(stream);
+        (void)hipSetDevice(prev);
+    };
+#define CLS_TRY(expr)                                                                                     \
+    do {                                                                                                  \
+        hipError_t e_ = (expr);                                                                           \
+        if (e_ != hipSuccess) { cleanup(); return fail(e_ == hipErrorOutOfMemory ? CLS_E_NOMEM : CLS_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); } \
+    } while (0)
+    try {
+        CLS_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+        // bounded device footprint: chunks of <= 4M reads and <= 1 GiB of bases
+        const uint32_t max_reads = 4u << 20;
+        const uint64_t max_bytes = 1ull << 30;
+        std::vector<uint64_t> rel;
+        uint64_t cap_bytes = 0;
+        uint32_t cap_reads = 0;
+        for (uint32_t first = 0; first < n;) {
+            uint32_t cnt = 0;
+            while (first + cnt < n && cnt < max_reads && (cnt == 0 || offsets[first + cnt + 1] - offsets[first] <= max_bytes)) ++cnt;
+            const uint64_t nbytes = offsets[first + cnt] - offsets[first];
+            if (nbytes > cap_bytes || !d_bases) {
+                if (d_bases) { (void)hipFree(d_bases); d_bases = nullptr; }
+                CLS_TRY(hipMalloc(&d_bases, nbytes ? nbytes : 16));
+                cap_bytes = nbytes;
+            }
+            if (cnt > cap_reads) {
+                if (d_off) { (void)hipFree(d_off); d_off = nullptr; }
+                if (d_out) { (void)hipFree(d_out); d_out = nullptr; }
+                if (d_stats) { (void)hipFree(d_stats); d_stats = nullptr; }
+                CLS_TRY(hipMalloc(&d_off, ((size_t)cnt + 1) * 8));
+                CLS_TRY(hipMalloc(&d_out, (size_t)cnt * sizeof(cls_placement)));
+                if (stats) CLS_TRY(hipMalloc(&d_stats, (size_t)cnt * sizeof(cls_query_stats)));
+                cap_reads = cnt;
+            }
+            rel.resize((size_t)cnt + 1);
+            for (uint32_t i = 0; i <= cnt; ++i) rel[i] = offsets[first + i] - offsets[first];
+            if (nbytes) CLS_TRY(hipMemcpyAsync(d_bases, bases + offsets[first], nbytes, hipMemcpyHostToDevice, stream));
+            CLS_TRY(hipMemcpyAsync(d_off, rel.data(), ((size_t)cnt + 1) * 8, hipMemcpyHostToDevice, stream));
+            rc = cls_place_batch_device(db, d_bases, d_off, cnt, params, d_out, d_stats, stream);
+            if (rc != CLS_OK) { cleanup(); return rc; }
+            CLS_TRY(hipMemcpyAsync(out + first, d_out, (size_t)cnt * sizeof(cls_placement), hipMemcpyDeviceToHost, stream));
+            if (stats) CLS_TRY(hipMemcpyAsync(stats + first, d_stats, (size_t)cnt * sizeof(cls_query_stats), hipMemcpyDeviceToHost, stream));
+            CLS_TRY(hipStreamSynchronize(stream));
+            first += cnt;
+        }
+    } catch (const std::bad_alloc&) {
+        cleanup();
+        return fail(CLS_E_NOMEM, "cls_place_batch: out of host memory");
+    } catch (...) {
+        cleanup();
+        return fail(CLS_E_INTERNAL, "cls_place_batch: unknown exception");
+    }
+    cleanup();
+    return CLS_OK;
+#undef CLS_TRY
+}
+
+extern "C" int cls_place_batch(cls_db* db, const char* bases, const uint64_t* offsets, uint32_t n,
+                               const cls_params* params, cls_placement* out) {
+    return place_host(db, bases, offsets, n, params, out, nullptr);
+}
+
+extern "C" int cls_place_batch_stats(cls_db* db, const char* bases, const uint64_t* offsets, uint32_t n,
+                                     const cls_params* params, cls_placement* out, cls_query_stats* stats) {
+    if (!stats) return fail(CLS_E_INVALID_ARG, "cls_place_batch_stats: stats is null");
+    return place_host(db, bases, offsets, n, params, out, stats);
+}

@@ -1,0 +1,229 @@
+// Host-side encoder: borrowed `cls_db_desc` (the reference's Tree + KmersMap,
+// flattened) -> the HBM layout of cls_device.h.  Runs once per database at
+// cls_db_create(); nothing here is on the timed path.
+#include "cls_db.h"
+
+#include <algorithm>
+#include <atomic>
+#include <functional>
+#include <thread>
+
+namespace cls {
+
+namespace {
+
+void parallel_chunks(uint64_t n, unsigned n_threads, const std::function<void(unsigned, uint64_t, uint64_t)>& fn) {
+    if (n_threads <= 1 || n < 4096) {
+        fn(0, 0, n);
+        return;
+    }
+    std::vector<std::thread> th;
+    for (unsigned t = 0; t < n_threads; ++t)
+        th.emplace_back([=, &fn] { fn(t, n * t / n_threads, n * (t + 1) / n_threads); });
+    for (auto& x : th) x.join();
+}
+
+}  // namespace
+
+int encode_db(const cls_db_desc* d, EncodedDb& E, std::string& err) {
+    // ---- 0. argument checks ---------------------------------------------------
+    if (!d) { err = "null descriptor"; return CLS_E_INVALID_ARG; }
+    if (d->abi_version != CLS_ABI_VERSION) { err = "cls_db_desc.abi_version mismatch"; return CLS_E_INVALID_ARG; }
+    if (d->n_nodes == 0 || !d->nodes) { err = "empty node table"; return CLS_E_BAD_TREE; }
+    if (d->k_size == 0 || d->k_size > MAX_K) { err = "kSize must be in [1, " + std::to_string(MAX_K) + "]"; return CLS_E_BAD_DB; }
+    if (d->n_buckets >= (1ULL << LOC_BUCKET_BITS)) { err = "too many minimizer buckets (>= 2^24)"; return CLS_E_BAD_DB; }
+    if ((d->n_buckets && (!d->bucket_key || !d->bucket_kmer_off)) || (d->n_kmers && (!d->kmer_hash || !d->kmer_node_off)) ) {
+        err = "null k-mer map array"; return CLS_E_INVALID_ARG;
+    }
+    if (d->n_buckets) {
+        if (d->bucket_kmer_off[0] != 0 || d->bucket_kmer_off[d->n_buckets] != d->n_kmers) { err = "bucket_kmer_off does not span [0, n_kmers]"; return CLS_E_BAD_DB; }
+        for (uint64_t b = 0; b < d->n_buckets; ++b)
+            if (d->bucket_kmer_off[b] > d->bucket_kmer_off[b + 1]) { err = "bucket_kmer_off not monotone"; return CLS_E_BAD_DB; }
+    } else if (d->n_kmers) { err = "k-mers without buckets"; return CLS_E_BAD_DB; }
+    for (uint64_t j = 0; j < d->n_kmers; ++j)
+        if (d->kmer_node_off[j] > d->kmer_node_off[j + 1]) { err = "kmer_node_off not monotone"; return CLS_E_BAD_DB; }
+    if (d->n_kmers && d->kmer_node_off[d->n_kmers] && !d->node_ids) { err = "null node_ids"; return CLS_E_INVALID_ARG; }
+
+    const uint32_t N = d->n_nodes;
+    // ---- 1. validate the row table is a tree rooted at row 0 -------------------
+    std::vector<uint32_t> order;  // engine row -> caller row (BFS, non-LEAF children first)
+    order.reserve(N);
+    {
+        std::vector<uint8_t> seen(N, 0);
+        order.push_back(0);
+        seen[0] = 1;
+        for (size_t i = 0; i < order.size(); ++i) {
+            const cls_node& n = d->nodes[order[i]];
+            if (n.kind > CLS_KIND_LEAF) { err = "node kind out of range"; return CLS_E_BAD_TREE; }
+            if (n.n_children == 0) continue;
+            if (!n.has_children) { err = "n_children > 0 with has_children == 0"; return CLS_E_BAD_TREE; }
+            if ((uint64_t)n.first_child + n.n_children > N || n.first_child == 0) { err = "child rows out of range"; return CLS_E_BAD_TREE; }
+            for (int pass = 0; pass < 2; ++pass)  // non-LEAF children first, each group in Clade.children order
+                for (uint32_t c = n.first_child; c < n.first_child + n.n_children; ++c) {
+                    bool leaf = d->nodes[c].kind == CLS_KIND_LEAF;
+                    if (leaf != (pass == 1)) continue;
+                    if (seen[c]) { err = "row is the child of two parents (not a tree)"; return CLS_E_BAD_TREE; }
+                    seen[c] = 1;
+                    order.push_back(c);
+                }
+        }
+        if (order.size() != N) { err = "rows unreachable from the root"; return CLS_E_BAD_TREE; }
+    }
+    std::vector<uint32_t> new_row(N);
+    for (uint32_t r = 0; r < N; ++r) new_row[order[r]] = r;
+    E.nodes.assign(N, DNode{});
+    for (uint32_t r = 0; r < N; ++r) {
+        const cls_node& n = d->nodes[order[r]];
+        DNode& o = E.nodes[r];
+        o.id = n.id;
+        o.n_children = n.n_children;
+        o.flags = n.has_children ? 1u : 0u;
+        o.n_nonleaf = 0;
+        o.first_child = 0;
+        if (n.n_children) {
+            uint32_t first = UINT32_MAX;
+            for (uint32_t c = n.first_child; c < n.first_child + n.n_children; ++c) {
+                first = std::min(first, new_row[c]);
+                if (d->nodes[c].kind != CLS_KIND_LEAF) o.n_nonleaf++;
+            }
+            o.first_child = first;
+            E.max_nonleaf_arity = std::max(E.max_nonleaf_arity, o.n_nonleaf);
+        }
+    }
+    // ---- 2. DFS pre-order + subtree sizes in the engine's child order ---------
+    std::vector<uint32_t> parent_pre(N, UINT32_MAX), size_by_pre(N, 1), row_by_pre(N);
+    std::vector<uint8_t> leaf_by_pre(N, 0);
+    {
+        struct Fr { uint32_t row, next; };
+        std::vector<Fr> st;
+        st.push_back({0, 0});
+        uint32_t counter = 0;
+        E.nodes[0].pre = counter++;
+        row_by_pre[0] = 0;
+        uint32_t depth = 0;
+        while (!st.empty()) {
+            Fr& f = st.back();
+            DNode& n = E.nodes[f.row];
+            if (f.next < n.n_children) {
+                uint32_t c = n.first_child + f.next++;
+                E.nodes[c].pre = counter++;
+                row_by_pre[E.nodes[c].pre] = c;
+                parent_pre[E.nodes[c].pre] = n.pre;
+                st.push_back({c, 0});
+                depth = std::max<uint32_t>(depth, (uint32_t)st.size() - 1);
+            } else {
+                n.size = counter - n.pre;
+                size_by_pre[n.pre] = n.size;
+                st.pop_back();
+            }
+        }
+        E.max_depth = depth;
+        for (uint32_t r = 0; r < N; ++r) leaf_by_pre[E.nodes[r].pre] = d->nodes[order[r]].kind == CLS_KIND_LEAF;
+    }
+    // ---- 3. clade id -> pre ------------------------------------------------------
+    std::vector<std::pair<uint64_t, uint32_t>> id2pre(N);
+    for (uint32_t r = 0; r < N; ++r) id2pre[r] = {E.nodes[r].id, E.nodes[r].pre};
+    std::sort(id2pre.begin(), id2pre.end());
+    for (uint32_t r = 1; r < N; ++r)
+        if (id2pre[r].first == id2pre[r - 1].first) { err = "duplicate clade id " + std::to_string(id2pre[r].first); return CLS_E_BAD_TREE; }
+    auto pre_of = [&](uint64_t id) -> uint32_t {
+        auto it = std::lower_bound(id2pre.begin(), id2pre.end(), std::make_pair(id, (uint32_t)0));
+        return (it != id2pre.end() && it->first == id) ? it->second : UINT32_MAX;
+    };
+    // ---- 4. per k-mer: node set -> sorted pre list -> tips / explicit list -------
+    const uint64_t NK = d->n_kmers;
+    std::vector<uint32_t> bucket_of(NK);
+    for (uint64_t b = 0; b < d->n_buckets; ++b)
+        for (uint64_t j = d->bucket_kmer_off[b]; j < d->bucket_kmer_off[b + 1]; ++j) bucket_of[j] = (uint32_t)b;
+    unsigned nt = std::max(1u, std::min(32u, std::thread::hardware_concurrency()));
+    std::vector<std::vector<uint32_t>> chunk_words(nt);
+    std::vector<uint64_t> local_off(NK);  // offset of k-mer j inside its chunk
+    std::vector<std::pair<uint64_t, uint64_t>> chunk_range(nt, {0, 0});
+    std::atomic<uint64_t> n_closed{0};
+    parallel_chunks(NK, nt, [&](unsigned t, uint64_t lo, uint64_t hi) {
+        chunk_range[t] = {lo, hi};
+        std::vector<uint32_t>& W = chunk_words[t];
+        std::vector<uint32_t> P, stk;
+        uint64_t closed_cnt = 0;
+        for (uint64_t j = lo; j < hi; ++j) {
+            P.clear();
+            for (uint64_t i = d->kmer_node_off[j]; i < d->kmer_node_off[j + 1]; ++i) {
+                uint32_t p = pre_of(d->node_ids[i]);
+                if (p != UINT32_MAX) P.push_back(p);  // ids that are no clade of this tree can never be asked for
+            }
+            std::sort(P.begin(), P.end());
+            P.erase(std::unique(P.begin(), P.end()), P.end());
+            bool has_root = !P.empty() && P[0] == 0;
+            bool closed = true;
+            stk.clear();
+            uint32_t n_leaf = 0;
+            for (uint32_t x : P) {
+                n_leaf += leaf_by_pre[x];
+                if (!closed) continue;
+                while (!stk.empty() && x >= stk.back() + size_by_pre[stk.back()]) stk.pop_back();
+                if (x != 0 && (stk.empty() || stk.back() != parent_pre[x])) closed = false;
+                stk.push_back(x);
+            }
+            local_off[j] = W.size();
+            size_t hdr = W.size();
+            W.push_back(0);
+            W.push_back(n_leaf);
+            uint32_t n_el = 0;
+            for (size_t i = 0; i < P.size(); ++i) {
+                uint32_t x = P[i];
+                if (x == 0) continue;  // the root is carried by POST_HAS_ROOT
+                if (closed && i + 1 < P.size() && P[i + 1] < x + size_by_pre[x]) continue;  // has a member below: not a tip
+                W.push_back(x);
+                ++n_el;
+            }
+            W[hdr] = n_el | (has_root ? POST_HAS_ROOT : 0) | (closed ? POST_CLOSED : 0);
+            closed_cnt += closed;
+        }
+        n_closed += closed_cnt;
+    });
+    // chunks that were not run (single-thread fallback) stay empty
+    std::vector<uint64_t> chunk_base(nt + 1, 0);
+    for (unsigned t = 0; t < nt; ++t) chunk_base[t + 1] = chunk_base[t] + chunk_words[t].size();
+    const uint64_t total_words = chunk_base[nt];
+    if (total_words >= (1ULL << 40)) { err = "postings exceed 2^40 words"; return CLS_E_BAD_DB; }
+    E.postings.resize(total_words + 4);  // small tail pad: speculative reads past an empty list stay in bounds
+    for (unsigned t = 0; t < nt; ++t) {
+        std::copy(chunk_words[t].begin(), chunk_words[t].end(), E.postings.begin() + chunk_base[t]);
+        std::vector<uint32_t>().swap(chunk_words[t]);
+    }
+    std::vector<uint64_t> kmer_off(NK);
+    for (unsigned t = 0; t < nt; ++t)
+        for (uint64_t j = chunk_range[t].first; j < chunk_range[t].second; ++j) kmer_off[j] = chunk_base[t] + local_off[j];
+    // ---- 5. hash table -------------------------------------------------------------
+    uint64_t cap = 16;
+    while (cap < 2 * NK) cap <<= 1;
+    if (cap >= (1ULL << 32)) { err = "k-mer table exceeds 2^32 slots"; return CLS_E_BAD_DB; }
+    E.table.assign(cap, Slot{0, SLOT_EMPTY});
+    const uint64_t mask = cap - 1;
+    for (uint64_t j = 0; j < NK; ++j) {
+        uint64_t h = d->kmer_hash[j];
+        uint64_t off = kmer_off[j];
+        uint64_t i = h & mask;
+        while (E.table[i].loc != SLOT_EMPTY) {
+            if (E.table[i].hash == h) {
+                // HashMap<MinimizerKey, HashMap<u64,..>>: the same k-mer hash under two buckets (or twice
+                // in one bucket) cannot come out of `cls build-db` short of a 64-bit murmur collision.
+                err = "k-mer hash " + std::to_string(h) + " occurs more than once in the index (unsupported)";
+                return CLS_E_BAD_DB;
+            }
+            i = (i + 1) & mask;
+        }
+        E.table[i] = Slot{h, (off << LOC_BUCKET_BITS) | bucket_of[j]};
+    }
+    E.bucket_key.assign(d->bucket_key, d->bucket_key + d->n_buckets);
+    if (E.bucket_key.empty()) E.bucket_key.push_back(0);
+    E.k = (uint32_t)d->k_size;
+    E.m = (uint32_t)std::min<uint64_t>(d->m_size, UINT32_MAX);
+    E.m_eff = (uint32_t)std::min<uint64_t>(d->m_size, d->k_size);
+    E.n_kmers = NK;
+    E.n_closed = n_closed.load();
+    E.root_has_children = d->nodes[0].has_children != 0;
+    return CLS_OK;
+}
+
+}  // namespace cls

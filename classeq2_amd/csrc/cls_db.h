@@ -1,0 +1,26 @@
+// Host-side encoded database (see cls_db.cpp) before upload.
+#pragma once
+#include <string>
+#include <vector>
+
+#include "cls_device.h"
+
+namespace cls {
+
+constexpr uint64_t MAX_K = 1024;
+
+struct EncodedDb {
+    std::vector<DNode> nodes;
+    std::vector<Slot> table;
+    std::vector<uint32_t> postings;
+    std::vector<uint64_t> bucket_key;
+    uint32_t k = 0, m = 0, m_eff = 0;
+    uint32_t max_depth = 0, max_nonleaf_arity = 0;
+    uint64_t n_kmers = 0, n_closed = 0;
+    bool root_has_children = false;
+};
+
+// Validates `d` and fills `E`; returns CLS_OK or a CLS_E_* code with `err` set.
+int encode_db(const cls_db_desc* d, EncodedDb& E, std::string& err);
+
+}  // namespace cls

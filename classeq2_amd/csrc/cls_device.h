@@ -1,0 +1,79 @@
+// Device-side layout of the placement index (what lives in HBM) and the
+// host<->kernel contract.  See DESIGN.md "Data layout in HBM".
+#pragma once
+#include <stdint.h>
+
+#include "cls_place.h"
+
+namespace cls {
+
+// ---- tree -------------------------------------------------------------------
+// One 32-byte row per clade, in the engine's own BFS order in which every
+// node's non-LEAF children come first and are consecutive rows.  `pre` is the
+// node's index in the DFS pre-order that visits children in that same order,
+// `size` its subtree size, so subtree(v) == pre interval [pre, pre+size) and
+// the non-LEAF children of v tile [pre+1, ...) back to back.
+struct DNode {
+    uint32_t pre;
+    uint32_t size;
+    uint32_t first_child;   // row of the first (non-LEAF first) child
+    uint32_t n_nonleaf;     // children whose kind != LEAF (clade.rs:166-172)
+    uint64_t id;            // Clade.id
+    uint32_t n_children;
+    uint32_t flags;         // bit0: has_children (children: Some(..))
+};
+static_assert(sizeof(DNode) == 32, "DNode");
+
+// ---- k-mer table --------------------------------------------------------------
+// Open addressing, linear probing, power-of-two capacity, load <= 0.5.
+// key  = murmur3_x64_128(kmer,0).0 (kmers_map.rs:157-159)
+// loc  = postings word offset (40 bits) << 24 | minimizer-bucket index (24 bits)
+struct Slot {
+    uint64_t hash;
+    uint64_t loc;
+};
+static_assert(sizeof(Slot) == 16, "Slot");
+constexpr uint64_t SLOT_EMPTY = ~0ULL;
+constexpr int LOC_BUCKET_BITS = 24;
+constexpr uint64_t LOC_BUCKET_MASK = (1ULL << LOC_BUCKET_BITS) - 1;
+
+// ---- postings -----------------------------------------------------------------
+// Per k-mer, at word offset `off` of the u32 postings array:
+//   w0 = n_elems | POST_HAS_ROOT | POST_CLOSED
+//   w1 = number of LEAF-kind ids in the original node set (statistics only)
+//   n_elems ascending pre-order indices, the root (pre 0) stripped:
+//     POST_CLOSED : the node set was closed under `parent` -> only its TIPS
+//                   (members with no member below them) are stored;
+//                   v in set  <=>  some tip in [pre(v), pre(v)+size(v))
+//     otherwise   : every member is stored; v in set <=> pre(v) stored
+constexpr uint32_t POST_HAS_ROOT = 1u << 31;
+constexpr uint32_t POST_CLOSED = 1u << 30;
+constexpr uint32_t POST_LEN_MASK = (1u << 30) - 1;
+constexpr uint32_t POST_HEADER_WORDS = 2;
+
+struct DbDev {
+    const DNode* nodes;
+    const Slot* table;
+    const uint32_t* postings;
+    const uint64_t* bucket_key;
+    uint64_t table_mask;
+    uint32_t n_nodes;
+    uint32_t n_buckets;
+    uint32_t k;          // kSize
+    uint32_t m_eff;      // min(mSize, kSize): chars().take(m), kmers_map.rs:11
+    uint32_t max_nonleaf_arity;
+    uint32_t pad_;
+};
+
+// Resolved Option<> arguments (place_sequence.rs:64-75)
+struct PlaceParams {
+    int32_t max_iterations;
+    uint32_t remove_intersection;
+    double min_match_coverage;
+};
+
+// Per-read k-mer capacity of the widest kernel (reads beyond it are reported
+// as CLS_ERR_READ_TOO_LONG).
+constexpr uint32_t MAX_READ_KMERS = 64 * 5;
+
+}  // namespace cls

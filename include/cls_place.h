@@ -176,6 +176,9 @@ int cls_device_count(void);
  * Replaces nothing in the reference (it keeps the Tree in host hash maps,
  * ports/lib/src/functions/load_database.rs:9-53); called once after it. */
 int cls_db_create(const cls_db_desc* d, int device, cls_db** out);
+/* Host-only: run the validation + re-encoding of cls_db_create without
+ * touching a device (CLS_OK, or the code cls_db_create would return). */
+int cls_db_validate(const cls_db_desc* d);
 void cls_db_destroy(cls_db* db);
 int cls_db_info_get(const cls_db* db, cls_db_info* info);
 

@@ -496,13 +496,13 @@ def sequence_content_by_channel(text: str) -> List[Tuple[str, str]]:
     out: List[Tuple[str, str]] = []
     header = ""
     sequence = ""
-    # BufRead::lines(): split on '\n', strip one trailing '\r'
-    lines = text.split("\n")
-    if lines and lines[-1] == "":
-        lines.pop()
+    # BufRead::lines(): split at '\n'; a line that WAS terminated by '\n' also
+    # loses one trailing '\r' (an unterminated last line keeps it)
+    parts = text.split("\n")
+    lines = [p[:-1] if p.endswith("\r") else p for p in parts[:-1]]
+    if parts[-1] != "":
+        lines.append(parts[-1])
     for line in lines:
-        if line.endswith("\r"):
-            line = line[:-1]
         if line == "":
             continue
         if line.startswith(">"):

@@ -1,0 +1,67 @@
+"""Shared test helpers (test infrastructure; may use oracle/)."""
+import numpy as np
+
+from classeq2_amd import _abi
+from classeq2_amd.flatdb import FlatDb
+
+PARAM_SETS = [
+    dict(),
+    dict(remove_intersection=True),
+    dict(min_match_coverage=1.0),
+    dict(min_match_coverage=0.0, remove_intersection=False),
+    dict(max_iterations=2),
+    dict(max_iterations=0),
+]
+
+
+def records_equal(a: np.ndarray, b: np.ndarray):
+    """Field-wise comparison of cls_placement arrays (padding ignored)."""
+    bad = np.zeros(len(a), dtype=bool)
+    for f in ("status", "one", "rest", "levels", "clade_id"):
+        bad |= a[f] != b[f]
+    return np.nonzero(bad)[0]
+
+
+def stats_equal(a: np.ndarray, b: np.ndarray):
+    bad = np.zeros(len(a), dtype=bool)
+    for f in ("n_query_kmers", "n_matched", "n_with_root", "leaf_postings"):
+        bad |= a[f] != b[f]
+    return np.nonzero(bad)[0]
+
+
+def describe(rec) -> str:
+    return f"{_abi.STATUS_NAMES[int(rec['status'])]} one={rec['one']} rest={rec['rest']} levels={rec['levels']} clade={rec['clade_id']}"
+
+
+def drop_random_nodes(flat: FlatDb, frac: float, seed: int, keep_root_frac: float = 0.9) -> FlatDb:
+    """Make node sets that are NOT closed under `parent` (arbitrary DB files are
+    allowed at the boundary): delete a random fraction of the ids of every set."""
+    rng = np.random.default_rng(seed)
+    root_id = int(flat.nodes[0]["id"])
+    keep = rng.random(len(flat.node_ids)) >= frac
+    is_root = flat.node_ids == root_id
+    keep[is_root] = rng.random(int(is_root.sum())) < keep_root_frac
+    new_ids = flat.node_ids[keep]
+    csum = np.concatenate([[0], np.cumsum(keep)])
+    new_off = csum[flat.kmer_node_off.astype(np.int64)].astype(np.uint64)
+    return FlatDb(nodes=flat.nodes.copy(), k_size=flat.k_size, m_size=flat.m_size, bucket_key=flat.bucket_key.copy(),
+                  bucket_kmer_off=flat.bucket_kmer_off.copy(), kmer_hash=flat.kmer_hash.copy(),
+                  kmer_node_off=new_off, node_ids=new_ids)
+
+
+def ragged_reads(rng, synth, n, min_len, max_len, err=0.02, frac_random=0.05, lower_frac=0.1):
+    """Reads of varying length (incl. shorter than k and empty), some lower-case."""
+    lens = rng.integers(min_len, max_len + 1, size=n)
+    parts, offs = [], [0]
+    for i, L in enumerate(lens):
+        L = int(L)
+        if L == 0:
+            offs.append(offs[-1])
+            continue
+        b, _, _ = synth.reads(1, L, seed=int(rng.integers(1 << 30)), first=i, err=err, frac_random=frac_random)
+        if rng.random() < lower_frac:
+            b = b | 0x20  # lower-case
+        parts.append(b)
+        offs.append(offs[-1] + L)
+    bases = np.concatenate(parts) if parts else np.zeros(0, dtype=np.uint8)
+    return bases, np.array(offs, dtype=np.uint64)

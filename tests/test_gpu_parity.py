@@ -1,0 +1,99 @@
+"""GPU parity: HIP path (through the C-ABI) vs the oracle on the same seeded inputs."""
+import numpy as np
+import pytest
+
+from classeq2_amd import _abi, engine
+from classeq2_amd.synth import SynthDb
+from oracle import oracle_port as op
+from tests.helpers import PARAM_SETS, describe, drop_random_nodes, ragged_reads, records_equal, stats_equal
+
+pytestmark = pytest.mark.gpu
+
+CASES = [
+    # n_leaves, ref_len, k, m, collapse_prob, id_stride, id_offset, read_len
+    (40, 200, 6, 3, 0.0, 1, 0, 60),
+    (60, 300, 8, 4, 0.3, 3, 7, 80),
+    (100, 300, 10, 4, 0.5, 1, 0, 100),
+    (30, 120, 5, 0, 0.5, 5, 100, 40),
+    (50, 200, 7, 9, 0.0, 1, 0, 20),
+    (200, 500, 12, 4, 0.0, 1, 0, 150),
+    (150, 400, 35, 4, 0.1, 2, 1, 150),
+    (80, 300, 17, 4, 0.0, 1, 0, 120),
+]
+
+
+def _check(flat, bases, offsets, kw, threads=4):
+    with engine.PlacementDb(flat, device=0) as db:
+        got, gst = db.place_batch(bases, offsets, engine.make_params(**kw), want_stats=True)
+        got2 = db.place_batch(bases, offsets, engine.make_params(**kw))
+    want, wst = op.OraclePort(flat).place_batch(bases, offsets, op.make_params(**kw), threads=threads, want_stats=True)
+    bad = records_equal(got, want)
+    assert len(bad) == 0, f"{len(bad)} records differ, first {bad[0]}: got {describe(got[bad[0]])} want {describe(want[bad[0]])}"
+    assert len(records_equal(got, got2)) == 0, "stats and non-stats kernels disagree"
+    sb = stats_equal(gst, wst)
+    assert len(sb) == 0, f"{len(sb)} stats differ, first {sb[0]}: got {gst[sb[0]]} want {wst[sb[0]]}"
+    return got
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_synthetic_parity(case):
+    nl, rl, k, m, cp, stride, off, rdlen = case
+    s = SynthDb(nl, rl, k, m, collapse_prob=cp, id_stride=stride, id_offset=off)
+    bases, offsets, _ = s.reads(1500, rdlen, frac_random=0.05, err=0.02)
+    for kw in PARAM_SETS:
+        _check(s.flat, bases, offsets, kw)
+
+
+@pytest.mark.parametrize("frac", [0.05, 0.3])
+def test_non_closed_node_sets(frac):
+    """Node sets that are not closed under `parent` (explicit-list postings)."""
+    s = SynthDb(80, 300, 8, 4, collapse_prob=0.3)
+    flat = drop_random_nodes(s.flat, frac, seed=11)
+    bases, offsets, _ = s.reads(1500, 90, frac_random=0.05, err=0.02)
+    for kw in PARAM_SETS[:3]:
+        _check(flat, bases, offsets, kw)
+
+
+def test_ragged_and_edge_reads():
+    s = SynthDb(100, 400, 9, 4)
+    rng = np.random.default_rng(5)
+    bases, offsets = ragged_reads(rng, s, 800, 0, 168)
+    got = _check(s.flat, bases, offsets, {})
+    lens = np.diff(offsets.astype(np.int64))
+    assert (got["status"][lens < 9] == _abi.ERR_TOO_FEW_KMERS).all()
+    # invalid characters -> per-read error (the reference panics), only when len >= k
+    b2 = bases.copy()
+    o = offsets.astype(np.int64)
+    victims = [i for i in range(len(lens)) if lens[i] >= 9][:20]
+    for i in victims:
+        b2[o[i] + lens[i] // 2] = ord("N")
+    got2 = _check(s.flat, b2, offsets, {})
+    assert (got2["status"][victims] == _abi.ERR_INVALID_BASE).all()
+
+
+def test_read_too_long_reported():
+    s = SynthDb(50, 400, 8, 4)
+    bases, offsets, _ = s.reads(10, 300)
+    with engine.PlacementDb(s.flat, device=0) as db:
+        got = db.place_batch(bases, offsets)
+        assert 2 * (300 - 8 + 1) > db.info.max_read_kmers
+    assert (got["status"] == _abi.ERR_READ_TOO_LONG).all()
+
+
+def test_empty_batch_and_offsets_base():
+    s = SynthDb(50, 300, 8, 4)
+    with engine.PlacementDb(s.flat, device=0) as db:
+        out = db.place_batch(np.zeros(0, np.uint8), np.zeros(1, np.uint64))
+        assert len(out) == 0
+        bases, offsets, _ = s.reads(64, 100)
+        a = db.place_batch(bases, offsets)
+        pad = np.frombuffer(b"TTTTTTT", dtype=np.uint8)
+        b = db.place_batch(np.concatenate([pad, bases]), offsets + np.uint64(len(pad)))
+        assert len(records_equal(a, b)) == 0
+
+
+def test_c2_shape_parity_sample():
+    """BASELINE config C2 shape (1k leaves, k=8) on a 20k-read sample."""
+    s = SynthDb(1000, 1500, 8, 4)
+    bases, offsets, _ = s.reads(20000, 150)
+    _check(s.flat, bases, offsets, {}, threads=16)
