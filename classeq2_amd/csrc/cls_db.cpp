@@ -91,7 +91,7 @@ int encode_db(const cls_db_desc* d, EncodedDb& E, std::string& err) {
         }
     }
     // ---- 2. DFS pre-order + subtree sizes in the engine's child order ---------
-    std::vector<uint32_t> parent_pre(N, UINT32_MAX), size_by_pre(N, 1), row_by_pre(N);
+    std::vector<uint32_t> parent_pre(N, UINT32_MAX), size_by_pre(N, 1), row_by_pre(N), depth_by_pre(N, 0);
     std::vector<uint8_t> leaf_by_pre(N, 0);
     {
         struct Fr { uint32_t row, next; };
@@ -109,6 +109,7 @@ int encode_db(const cls_db_desc* d, EncodedDb& E, std::string& err) {
                 E.nodes[c].pre = counter++;
                 row_by_pre[E.nodes[c].pre] = c;
                 parent_pre[E.nodes[c].pre] = n.pre;
+                depth_by_pre[E.nodes[c].pre] = (uint32_t)st.size();
                 st.push_back({c, 0});
                 depth = std::max<uint32_t>(depth, (uint32_t)st.size() - 1);
             } else {
@@ -194,6 +195,55 @@ int encode_db(const cls_db_desc* d, EncodedDb& E, std::string& err) {
     std::vector<uint64_t> kmer_off(NK);
     for (unsigned t = 0; t < nt; ++t)
         for (uint64_t j = chunk_range[t].first; j < chunk_range[t].second; ++j) kmer_off[j] = chunk_base[t] + local_off[j];
+    // ---- 4b. split-tree form when the whole index allows it (see cls_device.h) -------
+    E.strictly_binary = true;
+    for (uint32_t r = 0; r < N; ++r)
+        if (E.nodes[r].n_children != 0 && E.nodes[r].n_children != 2) { E.strictly_binary = false; break; }
+    E.format = (E.strictly_binary && n_closed.load() == NK) ? FMT_SPLIT : FMT_LIST;
+    if (E.format == FMT_SPLIT) {
+        std::vector<uint64_t> rec_off(NK + 1, 0);
+        for (uint64_t j = 0; j < NK; ++j) rec_off[j + 1] = rec_off[j] + 1 + (E.postings[kmer_off[j]] & POST_LEN_MASK);
+        if (rec_off[NK] >= (1ULL << 32)) { err = "split-tree postings exceed 2^32 records"; return CLS_E_BAD_DB; }
+        std::vector<uint32_t> recs((rec_off[NK] + 1) * 4, 0);
+        parallel_chunks(NK, nt, [&](unsigned, uint64_t lo, uint64_t hi) {
+            std::vector<uint32_t> d, stk, L, R;
+            for (uint64_t j = lo; j < hi; ++j) {
+                const uint32_t* w = &E.postings[kmer_off[j]];
+                const uint32_t n = w[0] & POST_LEN_MASK;
+                const uint32_t* tip = w + POST_HEADER_WORDS;
+                const uint64_t base = rec_off[j];  // header record; tip i lives at base + 1 + i
+                d.assign(n, 0); L.assign(n, 0); R.assign(n, 0);
+                for (uint32_t i = 1; i < n; ++i) {  // depth of LCA(tip[i-1], tip[i])
+                    uint32_t a = tip[i - 1];
+                    while (!(tip[i] < a + size_by_pre[a])) a = parent_pre[a];
+                    d[i] = depth_by_pre[a];
+                }
+                stk.clear();
+                for (uint32_t i = 1; i < n; ++i) {  // Cartesian tree, shallowest LCA on top
+                    uint32_t last = 0;
+                    while (!stk.empty() && d[stk.back()] > d[i]) { last = stk.back(); stk.pop_back(); }
+                    L[i] = last;
+                    if (!stk.empty()) R[stk.back()] = i;
+                    stk.push_back(i);
+                }
+                const uint32_t root = stk.empty() ? 0 : stk.front();
+                uint32_t* h = &recs[base * 4];
+                h[0] = w[0];
+                h[1] = w[1];
+                h[2] = root ? (uint32_t)(base + 1 + root) : 0;
+                h[3] = n ? tip[n - 1] : 0;
+                for (uint32_t i = 0; i < n; ++i) {
+                    uint32_t* t = &recs[(base + 1 + i) * 4];
+                    t[0] = tip[i];
+                    t[1] = i ? tip[i - 1] : 0;
+                    t[2] = L[i] ? (uint32_t)(base + 1 + L[i]) : 0;
+                    t[3] = R[i] ? (uint32_t)(base + 1 + R[i]) : 0;
+                }
+            }
+        });
+        E.postings.swap(recs);
+        kmer_off.assign(rec_off.begin(), rec_off.end() - 1);
+    }
     // ---- 5. hash table -------------------------------------------------------------
     uint64_t cap = 16;
     while (cap < 2 * NK) cap <<= 1;

@@ -12,7 +12,9 @@ constexpr uint64_t MAX_K = 1024;
 struct EncodedDb {
     std::vector<DNode> nodes;
     std::vector<Slot> table;
-    std::vector<uint32_t> postings;
+    std::vector<uint32_t> postings;   // FMT_LIST words, or FMT_SPLIT records (4 words each)
+    uint32_t format = FMT_LIST;
+    bool strictly_binary = false;
     std::vector<uint64_t> bucket_key;
     uint32_t k = 0, m = 0, m_eff = 0;
     uint32_t max_depth = 0, max_nonleaf_arity = 0;

@@ -51,10 +51,31 @@ constexpr uint32_t POST_CLOSED = 1u << 30;
 constexpr uint32_t POST_LEN_MASK = (1u << 30) - 1;
 constexpr uint32_t POST_HEADER_WORDS = 2;
 
+// ---- postings, "split-tree" form (FMT_SPLIT) ----------------------------------
+// Used when EVERY node set is closed under `parent` AND every clade has exactly
+// zero or two children.  16-byte records; a k-mer owns 1 header + n tip records:
+//   header : {n_tips | POST_HAS_ROOT | POST_CLOSED, n_leaf_ids, root split (record index, 0 = none), last tip}
+//   tip i  : {tip[i], tip[i-1], L, R}
+// tip[] ascending pre-order indices.  Position i (1 <= i < n) doubles as the node
+// of the Cartesian tree over depth(LCA(tip[i-1], tip[i])): for the tips inside one
+// clade's interval the shallowest such LCA is where the clade's two children part
+// them, so L / R (absolute record indices, 0 = none) are the splits of the left /
+// right part.  Descending one level costs ONE 16-byte read per k-mer that has tips
+// on both sides, and none otherwise.
+struct TipRec {
+    uint32_t tip;
+    uint32_t tip_prev;
+    uint32_t l;
+    uint32_t r;
+};
+static_assert(sizeof(TipRec) == 16, "TipRec");
+
+enum : uint32_t { FMT_LIST = 0, FMT_SPLIT = 1 };
+
 struct DbDev {
     const DNode* nodes;
     const Slot* table;
-    const uint32_t* postings;
+    const uint32_t* postings;   // FMT_LIST: u32 words; FMT_SPLIT: TipRec records (16-byte units)
     const uint64_t* bucket_key;
     uint64_t table_mask;
     uint32_t n_nodes;
@@ -62,7 +83,7 @@ struct DbDev {
     uint32_t k;          // kSize
     uint32_t m_eff;      // min(mSize, kSize): chars().take(m), kmers_map.rs:11
     uint32_t max_nonleaf_arity;
-    uint32_t pad_;
+    uint32_t format;     // FMT_*; Slot.loc offsets are in words (LIST) or records (SPLIT)
 };
 
 // Resolved Option<> arguments (place_sequence.rs:64-75)

@@ -22,6 +22,9 @@ namespace cls {
 namespace {
 
 constexpr int WAVES_PER_BLOCK = 4;
+#ifndef MIN_WAVES_PER_EU
+#define MIN_WAVES_PER_EU 4
+#endif
 constexpr uint32_t SET_EMPTY = 0xFFFFFFFFu;
 
 __device__ __forceinline__ void wave_sync() {
@@ -43,6 +46,42 @@ __device__ __forceinline__ uint32_t lower_bound_g(const uint32_t* __restrict__ p
     return lo;
 }
 
+// For every slot s whose bit is set in `need`: move lo[s] (LO_SIDE) or hi[s] (!LO_SIDE) to
+// lower_bound(key) inside [lo[s], hi[s]).  All slots advance in lock step, one load per slot in
+// flight per round, so the dependent HBM/L2 round trips of a lane's k-mers overlap.
+template <int SLOTS, bool LO_SIDE>
+__device__ __forceinline__ void multi_lower_bound(const uint32_t* __restrict__ post, uint32_t (&lo)[SLOTS],
+                                                  uint32_t (&hi)[SLOTS], uint32_t key, uint32_t need) {
+    uint32_t other[SLOTS];  // the end of the range that must survive the search
+#pragma unroll
+    for (int s = 0; s < SLOTS; ++s) other[s] = LO_SIDE ? hi[s] : lo[s];
+    for (;;) {
+        uint32_t mid[SLOTS], v[SLOTS];
+        bool any = false;
+#pragma unroll
+        for (int s = 0; s < SLOTS; ++s) {
+            mid[s] = lo[s] + ((hi[s] - lo[s]) >> 1);
+            v[s] = 0;
+            if (((need >> s) & 1u) && lo[s] < hi[s]) { v[s] = post[mid[s]]; any = true; }
+        }
+        if (!any) break;
+#pragma unroll
+        for (int s = 0; s < SLOTS; ++s)
+            if (((need >> s) & 1u) && lo[s] < hi[s]) { if (v[s] < key) lo[s] = mid[s] + 1; else hi[s] = mid[s]; }
+    }
+#pragma unroll
+    for (int s = 0; s < SLOTS; ++s)
+        if ((need >> s) & 1u) { if (LO_SIDE) hi[s] = other[s]; else lo[s] = other[s]; }
+}
+
+// rare, kept out of line: the interval has stored elements on both sides of it
+__device__ __forceinline__ bool member_search(const uint32_t* __restrict__ post, uint32_t lo, uint32_t hi, bool closed,
+                                           uint32_t c0, uint32_t c1) {
+    const uint32_t i = lower_bound_g(post, lo, hi, c0);
+    const uint32_t v = post[i];
+    return closed ? (v < c1) : (v == c0);
+}
+
 // Is clade c = pre interval [c0, c1) a member of the k-mer's node set?
 // The k-mer's stored elements inside the current parent's interval are
 // post[lo, hi), with vlo = post[lo], vhi = post[hi-1] cached in registers.
@@ -51,14 +90,41 @@ __device__ __forceinline__ bool member_of(const uint32_t* __restrict__ post, uin
     if (vhi < c0 || vlo >= c1) return false;
     if (closed) {  // tips: member <=> a tip inside [c0, c1)
         if (vlo >= c0 || vhi < c1) return true;
-        uint32_t i = lower_bound_g(post, lo, hi, c0);  // vlo < c0 and vhi >= c1: look inside
-        return post[i] < c1;
+        return member_search(post, lo, hi, true, c0, c1);  // vlo < c0 and vhi >= c1: look inside
     }
     // explicit list: member <=> c0 itself is stored
     if (vlo == c0 || vhi == c0) return true;
     if (vlo > c0) return false;
-    uint32_t i = lower_bound_g(post, lo, hi, c0);
-    return post[i] == c0;
+    return member_search(post, lo, hi, false, c0, c1);
+}
+
+// MurmurHash3_x64_128(bytes[0..len), seed 0).0 of the k-mer, and of its first `mlen` bytes
+// (the "minimizer" prefix, kmers_map.rs:10-13; hash("") == 0 covers mSize == 0, :131-134),
+// in one pass over the bytes.  Byte-at-a-time on purpose: small register footprint.
+__device__ __forceinline__ void hash_kmer_and_prefix(const uint8_t* p, uint32_t len, uint32_t mlen, uint64_t& h_out,
+                                                     uint64_t& mz_out) {
+    Mur3 m, pm;  // full k-mer / prefix
+    uint64_t k1 = 0, k2 = 0;
+    bool pm_done = (mlen == 0);
+    uint64_t mz = 0;  // murmur3 of the empty message is 0
+#pragma unroll 1
+    for (uint32_t i = 0; i < len; ++i) {
+        const uint32_t pos = i & 15u;
+        const uint64_t b = p[i];
+        if (pos < 8) k1 |= b << (8 * pos); else k2 |= b << (8 * (pos - 8));
+        if (!pm_done && i + 1 == mlen) {  // the prefix ends inside this block: finish its hash from the partial words
+            const uint32_t t = mlen & 15u;
+            mz = (t == 0) ? (pm.block(k1, k2), pm.finish(0, 0, 0, mlen)) : pm.finish(k1, k2, t, mlen);
+            pm_done = true;
+        }
+        if (pos == 15) {
+            m.block(k1, k2);
+            if (!pm_done) pm.block(k1, k2);
+            k1 = k2 = 0;
+        }
+    }
+    h_out = m.finish(k1, k2, len & 15u, len);
+    mz_out = mz;
 }
 
 struct WaveCtx {
@@ -79,10 +145,14 @@ __device__ __forceinline__ void write_record(cls_placement* out, uint32_t r, uin
     }
 }
 
+// Phases A0-A2 for one read, shared by both postings formats.  Returns false when the
+// read's record has already been written (error statuses); otherwise cx.ent[j] holds, for
+// query k-mer j < nk, the postings offset of its index entry if j is the FIRST query k-mer
+// with that hash and the entry passes the minimizer-bucket filter, else SET_EMPTY.
 template <int SLOTS, int SET_BITS, bool STATS>
-__device__ __forceinline__ void place_read(const DbDev db, const PlaceParams prm, const WaveCtx cx, const uint8_t* __restrict__ bases,
-                           uint64_t b0, uint64_t b1, uint32_t r, cls_placement* __restrict__ out,
-                           cls_query_stats* __restrict__ stats) {
+__device__ __forceinline__ bool match_phase(const DbDev& db, const WaveCtx& cx, const uint8_t* __restrict__ bases,
+                                            uint64_t b0, uint64_t b1, uint32_t r, cls_placement* __restrict__ out,
+                                            cls_query_stats* __restrict__ stats, uint32_t& nk_out) {
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t k = db.k;
     const uint64_t L64 = b1 - b0;
@@ -98,28 +168,32 @@ __device__ __forceinline__ void place_read(const DbDev db, const PlaceParams prm
     if (L64 < k) {
         put_stats(0, 0, 0, 0);
         write_record(out, r, CLS_ERR_TOO_FEW_KMERS, 0, 0, 0, 0);
-        return;
+        return false;
     }
     const uint64_t nk64 = 2 * (L64 - k + 1);
     if (nk64 > (uint64_t)(64 * SLOTS)) {
         put_stats(nk64 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)nk64, 0, 0, 0);
         write_record(out, r, CLS_ERR_READ_TOO_LONG, 0, 0, 0, 0);
-        return;
+        return false;
     }
     const uint32_t L = (uint32_t)L64, nf = L - k + 1, nk = 2 * nf;
-    // ---- A1. load, upper-case, validate (reverse_complement panics on non-ACGT, kmers_map.rs:440)
+    // ---- A1. load, upper-case, validate (reverse_complement panics on non-ACGT, kmers_map.rs:440);
+    // LDS holds the forward string followed by its reverse complement, so that query k-mer j
+    // (forward ones first, then those of the reverse complement, kmers_map.rs:387-395) is the
+    // k contiguous bytes at kmer_start(j).
     bool bad = false;
     for (uint32_t i = lane; i < L; i += 64) {
         uint8_t c = bases[b0 + i];
         if (c >= 'a' && c <= 'z') c -= 32;
         bad |= !(c == 'A' || c == 'C' || c == 'G' || c == 'T');
         cx.seq[i] = c;
+        cx.seq[2 * L - 1 - i] = c ^ ((c & 2) ? 0x04 : 0x15);  // A<->T, C<->G
     }
     for (uint32_t i = lane; i < (1u << SET_BITS); i += 64) cx.set[i] = SET_EMPTY;
     if (__ballot(bad)) {
         put_stats(0, 0, 0, 0);  // the reference dies inside build_kmer_from_string, before any count exists
         write_record(out, r, CLS_ERR_INVALID_BASE, 0, 0, 0, 0);
-        return;
+        return false;
     }
     wave_sync();
     // ---- A2. hash every k-mer + its minimizer prefix, probe the table, apply the
@@ -127,28 +201,15 @@ __device__ __forceinline__ void place_read(const DbDev db, const PlaceParams prm
     // (slot, lane); the surviving postings offsets are staged in LDS (cx.ent).
     const uint8_t* seq = cx.seq;
     const uint32_t m_eff = db.m_eff;
-    const uint32_t* __restrict__ post = db.postings;
-    auto hash_at = [&](uint32_t j, uint32_t len) -> uint64_t {
-        if (j < nf) {  // forward k-mer at j
-            const uint8_t* p = seq + j;
-            return murmur3_h1([p](uint32_t i) { return p[i]; }, len);
-        }
-        const uint8_t* p = seq + (L - 1 - (j - nf));  // k-mer at (j - nf) of the reverse complement
-        return murmur3_h1([p](uint32_t i) {
-            const uint8_t c = *(p - i);
-            return (uint8_t)(c == 'A' ? 'T' : c == 'C' ? 'G' : c == 'G' ? 'C' : 'A');
-        }, len);
-    };
-    uint32_t n_m = 0, n_root = 0;
-    uint64_t leafp = 0;
+    auto kmer_start = [&](uint32_t j) -> const uint8_t* { return seq + (j < nf ? j : L + (j - nf)); };
     for (uint32_t base = 0; base < nk; base += 64) {
         const uint32_t j = base + lane;
         bool hit = false;
         uint32_t tidx = 0;
         uint64_t loc = 0, mz = 0;
         if (j < nk) {
-            const uint64_t h = hash_at(j, k);
-            mz = hash_at(j, m_eff);  // hash("") == 0 when m == 0 (kmers_map.rs:131-134)
+            uint64_t h;
+            hash_kmer_and_prefix(kmer_start(j), k, m_eff, h, mz);
             uint64_t idx = h & db.table_mask;
             for (;;) {
                 const Slot sl = db.table[idx];
@@ -166,7 +227,11 @@ __device__ __forceinline__ void place_read(const DbDev db, const PlaceParams prm
             const int src = __ffsll((unsigned long long)pend) - 1;
             const uint64_t B = ((uint64_t)__shfl((uint32_t)(bk >> 32), src) << 32) | __shfl((uint32_t)bk, src);
             bool f = false;
-            for (uint32_t jj = lane; jj < nk; jj += 64) f |= hash_at(jj, m_eff) == B;
+            for (uint32_t jj = lane; jj < nk; jj += 64) {
+                uint64_t hh, mm;
+                hash_kmer_and_prefix(kmer_start(jj), m_eff, m_eff, hh, mm);
+                f |= mm == B;
+            }
             const bool any = __ballot(f) != 0;
             if ((int)lane == src) ok = any;
             pend &= pend - 1;
@@ -184,6 +249,28 @@ __device__ __forceinline__ void place_read(const DbDev db, const PlaceParams prm
         cx.ent[j] = ent;  // j < 64*SLOTS always
     }
     wave_sync();
+    nk_out = nk;
+    return true;
+}
+
+template <int SLOTS, int SET_BITS, bool STATS, bool BINARY>
+__device__ __forceinline__ void place_read(const DbDev db, const PlaceParams prm, const WaveCtx cx, const uint8_t* __restrict__ bases,
+                           uint64_t b0, uint64_t b1, uint32_t r, cls_placement* __restrict__ out,
+                           cls_query_stats* __restrict__ stats) {
+    const uint32_t lane = threadIdx.x & 63;
+    uint32_t nk = 0;
+    if (!match_phase<SLOTS, SET_BITS, STATS>(db, cx, bases, b0, b1, r, out, stats, nk)) return;
+    auto put_stats = [&](uint32_t nk_, uint32_t nm, uint32_t nr, uint64_t lp) {
+        if (STATS && stats && lane == 0) {
+            uint64_t* s = reinterpret_cast<uint64_t*>(stats + r);
+            s[0] = (uint64_t)nk_ | ((uint64_t)nm << 32);
+            s[1] = (uint64_t)nr;
+            s[2] = lp;
+        }
+    };
+    const uint32_t* __restrict__ post = db.postings;
+    uint32_t n_m = 0, n_root = 0;
+    uint64_t leafp = 0;
     // ---- A3. per-k-mer state: the stored elements below the root -------------------------
     uint32_t lo[SLOTS], hi[SLOTS], vlo[SLOTS], vhi[SLOTS];
     uint32_t act = 0, closedm = 0;
@@ -236,7 +323,7 @@ __device__ __forceinline__ void place_read(const DbDev db, const PlaceParams prm
         const uint32_t m = uniform(nodes[prow].n_nonleaf);
         uint32_t n_pass = 0, n_best = 0, best_row = 0;
         int32_t best_one = 0, best_rest = 0, best_diff = 0;
-        if (m <= 2) {
+        if (BINARY || m <= 2) {
             // ---- binary fast path: everything in registers -----------------------------
             uint32_t a0 = 0, a1 = 0, b0c = 0, b1c = 0;
             if (m >= 1) { a0 = uniform(nodes[fc].pre); a1 = a0 + uniform(nodes[fc].size); }
@@ -271,7 +358,7 @@ __device__ __forceinline__ void place_read(const DbDev db, const PlaceParams prm
                     ++n_pass;
                 }
             }
-        } else {
+        } else if (!BINARY) {
             // ---- general path (polytomies): per-child counters in memory --------------------
             for (uint32_t i = lane; i < m; i += 64) __hip_atomic_store(&cx.only[i], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             uint32_t nin[SLOTS], which[SLOTS];
@@ -342,26 +429,186 @@ __device__ __forceinline__ void place_read(const DbDev db, const PlaceParams prm
         prow = best_row;
         const uint32_t n0 = uniform(nodes[prow].pre) + 1;
         const uint32_t n1 = n0 - 1 + uniform(nodes[prow].size);
+        // narrow every k-mer's element range to the chosen clade's interval (n0-1 itself excluded);
+        // the binary searches of the SLOTS k-mers a lane owns run interleaved so that their
+        // dependent HBM/L2 round trips overlap.
+        uint32_t need_lo = 0, need_hi = 0;
 #pragma unroll
         for (int s = 0; s < SLOTS; ++s) {
             if (!(act & (1u << s))) continue;
-            bool keep = !(vhi[s] < n0 || vlo[s] >= n1);
-            if (keep && vlo[s] < n0) {
-                lo[s] = lower_bound_g(post, lo[s], hi[s], n0);  // < hi because vhi >= n0
-                vlo[s] = post[lo[s]];
-                keep = vlo[s] < n1;
+            if (vhi[s] < n0 || vlo[s] >= n1) { act &= ~(1u << s); continue; }
+            if (vlo[s] < n0) need_lo |= 1u << s;
+            if (vhi[s] >= n1) need_hi |= 1u << s;
+        }
+        if (__ballot(need_lo != 0)) {
+            multi_lower_bound<SLOTS, true>(post, lo, hi, n0, need_lo);  // < hi because vhi >= n0
+#pragma unroll
+            for (int s = 0; s < SLOTS; ++s) if (need_lo & (1u << s)) vlo[s] = post[lo[s]];
+#pragma unroll
+            for (int s = 0; s < SLOTS; ++s)
+                if ((need_lo & (1u << s)) && vlo[s] >= n1) { act &= ~(1u << s); need_hi &= ~(1u << s); }
+        }
+        if (__ballot(need_hi != 0)) {
+            multi_lower_bound<SLOTS, false>(post, lo, hi, n1, need_hi);  // > lo because vlo < n1
+#pragma unroll
+            for (int s = 0; s < SLOTS; ++s) if (need_hi & (1u << s)) vhi[s] = post[hi[s] - 1];
+        }
+    }
+}
+
+// ---- FMT_SPLIT: every node set closed, every clade has 0 or 2 children ---------------------
+// Per k-mer only (vlo, vhi, x) live in registers: the smallest / largest tip inside the current
+// clade and the record index of the split that parts them at their LCA (cls_device.h).
+template <int SLOTS, int SET_BITS, bool STATS>
+__device__ __forceinline__ void place_read_split(const DbDev db, const PlaceParams prm, const WaveCtx cx,
+                                                 const uint8_t* __restrict__ bases, uint64_t b0, uint64_t b1, uint32_t r,
+                                                 cls_placement* __restrict__ out, cls_query_stats* __restrict__ stats) {
+    const uint32_t lane = threadIdx.x & 63;
+    uint32_t nk = 0;
+    if (!match_phase<SLOTS, SET_BITS, STATS>(db, cx, bases, b0, b1, r, out, stats, nk)) return;
+    const uint4* __restrict__ recs = reinterpret_cast<const uint4*>(db.postings);
+    uint32_t vlo[SLOTS], vhi[SLOTS], x[SLOTS];
+    uint32_t act = 0, n_m = 0, n_root = 0;
+    uint64_t leafp = 0;
+#pragma unroll
+    for (int s = 0; s < SLOTS; ++s) {
+        const uint32_t j = s * 64 + lane;
+        const uint32_t off = (j < nk) ? cx.ent[j] : SET_EMPTY;
+        const bool is_new = off != SET_EMPTY;
+        bool has_root = false;
+        vlo[s] = vhi[s] = x[s] = 0;
+        if (is_new) {
+            const uint4 hd = recs[off];  // {n | flags, n_leaf_ids, root split, last tip}
+            if (STATS) leafp += hd.y;
+            has_root = (hd.x & POST_HAS_ROOT) != 0;
+            if (has_root && (hd.x & POST_LEN_MASK)) {
+                vlo[s] = recs[off + 1].x;
+                vhi[s] = hd.w;
+                x[s] = hd.z;
+                act |= 1u << s;
             }
-            if (keep && vhi[s] >= n1) {
-                hi[s] = lower_bound_g(post, lo[s], hi[s], n1);  // > lo because vlo < n1
-                vhi[s] = post[hi[s] - 1];
+        }
+        n_m += popc64(__ballot(is_new));
+        n_root += popc64(__ballot(is_new && has_root));
+    }
+    if (STATS && stats) {
+        for (int o = 32; o > 0; o >>= 1) leafp += ((uint64_t)__shfl_xor((uint32_t)(leafp >> 32), o) << 32) | __shfl_xor((uint32_t)leafp, o);
+        if (lane == 0) {
+            uint64_t* s = reinterpret_cast<uint64_t*>(stats + r);
+            s[0] = (uint64_t)nk | ((uint64_t)n_m << 32);
+            s[1] = (uint64_t)n_root;
+            s[2] = leafp;
+        }
+    }
+    // ---- B. thresholds (as in place_read) ------------------------------------------------------
+    if (n_m == 0) { write_record(out, r, CLS_UNCLASSIFIABLE_NO_MATCH, 0, 0, 0, 0); return; }
+    if (n_root == 0) { write_record(out, r, CLS_UNCLASSIFIABLE_NO_ROOT, 0, 0, 0, 0); return; }
+    const DNode* __restrict__ nodes = db.nodes;
+    if (!(nodes[0].flags & 1u)) { write_record(out, r, CLS_ERR_ROOT_NO_CHILDREN, 0, 0, 0, 0); return; }
+    {
+        const double expected = round((double)n_m * prm.min_match_coverage);
+        const uint64_t exp_usize = (expected != expected) ? 0ull : (uint64_t)expected;
+        if ((uint64_t)n_root < exp_usize) { write_record(out, r, CLS_UNCLASSIFIABLE_COVERAGE, (int32_t)n_root, 0, 0, 0); return; }
+    }
+    // ---- C. descent ---------------------------------------------------------------------------
+    const bool rm = prm.remove_intersection != 0;
+    uint32_t prow = 0;
+    int32_t iteration = 0;
+    for (;;) {
+        ++iteration;
+        if (iteration > prm.max_iterations) { write_record(out, r, CLS_ERR_MAX_ITER, 0, 0, (uint32_t)iteration, 0); return; }
+        const uint32_t fc = uniform(nodes[prow].first_child);
+        const uint32_t m = uniform(nodes[prow].n_nonleaf);  // 0, 1 or 2; the non-LEAF children come first
+        uint32_t a0 = 0, a1 = 0, bend = 0;
+        if (m >= 1) { a0 = uniform(nodes[fc].pre); a1 = a0 + uniform(nodes[fc].size); }
+        // the second child starts at a1 whatever its kind; it is scored only if it is not a LEAF
+        uint32_t cnt_a = 0, cnt_b = 0, both = 0;
+        if (m >= 1) {
+#pragma unroll
+            for (int s = 0; s < SLOTS; ++s) {
+                const bool on = (act >> s) & 1u;
+                const bool ina = on && vlo[s] < a1;             // vlo >= a0 always: the range lies below the parent
+                const bool inb = on && m == 2 && vhi[s] >= a1;  // vhi < end of the parent's interval always
+                cnt_a += popc64(__ballot(ina));
+                cnt_b += popc64(__ballot(inb));
+                both += popc64(__ballot(ina && inb));
             }
-            if (!keep) act &= ~(1u << s);
+        }
+        (void)bend;
+        const uint32_t U = cnt_a + cnt_b - both;
+        uint32_t n_pass = 0, n_best = 0, best = 0;
+        int32_t best_one = 0, best_rest = 0, best_diff = 0;
+        for (int c = 0; c < 2; ++c) {  // (one, rest) exactly as in place_read
+            const uint32_t cn = c ? cnt_b : cnt_a;
+            if (cn == 0) continue;
+            const uint32_t on = cn - both;
+            const int32_t one = (int32_t)(rm ? on : cn);
+            const int32_t rest = (int32_t)(rm ? U - cn : U - on);
+            if (one > rest) {
+                const int32_t diff = one - rest;
+                if (n_pass == 0 || diff > best_diff) { best_diff = diff; n_best = 1; best = c; best_one = one; best_rest = rest; }
+                else if (diff == best_diff) ++n_best;
+                ++n_pass;
+            }
+        }
+        if (n_pass == 0) {
+            if (iteration == 1) write_record(out, r, CLS_UNCLASSIFIABLE_LEVEL1, 0, 0, 1, 0);
+            else write_record(out, r, CLS_MAX_RESOLUTION, 0, 0, (uint32_t)iteration, nodes[prow].id);
+            return;
+        }
+        if (n_pass > 1 && n_best != 1) {
+            write_record(out, r, CLS_INCONCLUSIVE, (int32_t)n_pass, 0, (uint32_t)iteration, nodes[prow].id);
+            return;
+        }
+        const uint32_t crow = fc + best;
+        if (uniform(nodes[crow].n_nonleaf) == 0) {
+            write_record(out, r, CLS_IDENTITY_FOUND, best_one, best_rest, (uint32_t)iteration, nodes[crow].id);
+            return;
+        }
+        prow = crow;
+        // narrow to the chosen clade: ONE 16-byte read for a k-mer with tips on both sides, none otherwise
+        if (best == 0) {
+#pragma unroll
+            for (int s = 0; s < SLOTS; ++s) {
+                if (!((act >> s) & 1u)) continue;
+                if (vlo[s] >= a1 || vlo[s] == a0) { act &= ~(1u << s); continue; }  // nothing strictly below clade a
+                if (vhi[s] >= a1) { const uint4 t = recs[x[s]]; vhi[s] = t.y; x[s] = t.z; }
+            }
+        } else {
+#pragma unroll
+            for (int s = 0; s < SLOTS; ++s) {
+                if (!((act >> s) & 1u)) continue;
+                if (vhi[s] < a1) { act &= ~(1u << s); continue; }
+                if (vlo[s] < a1) { const uint4 t = recs[x[s]]; vlo[s] = t.x; x[s] = t.w; }
+                if (vlo[s] == a1) act &= ~(1u << s);  // the clade itself is the tip: nothing below it
+            }
         }
     }
 }
 
 template <int SLOTS, int SET_BITS, bool STATS>
-__global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void place_wave_kernel(DbDev db, PlaceParams prm,
+__global__ __launch_bounds__(64 * WAVES_PER_BLOCK, MIN_WAVES_PER_EU) void place_split_kernel(
+    DbDev db, PlaceParams prm, const uint8_t* __restrict__ bases, const uint64_t* __restrict__ offsets, uint32_t n_reads,
+    cls_placement* __restrict__ out, cls_query_stats* __restrict__ stats, uint32_t seq_cap) {
+    extern __shared__ __align__(16) uint8_t smem[];
+    const uint32_t wave = threadIdx.x >> 6;
+    const uint32_t per_wave = seq_cap + (4u << SET_BITS) + 4u * 64 * SLOTS;
+    WaveCtx cx;
+    cx.seq = smem + wave * per_wave;
+    cx.set = reinterpret_cast<uint32_t*>(cx.seq + seq_cap);
+    cx.ent = cx.set + (1u << SET_BITS);
+    cx.cnt = cx.only = nullptr;
+    const uint32_t gw = blockIdx.x * WAVES_PER_BLOCK + wave;
+    const uint32_t n_waves = gridDim.x * WAVES_PER_BLOCK;
+    for (uint32_t r = gw; r < n_reads; r += n_waves) {
+        const uint64_t b0 = offsets[r], b1 = offsets[r + 1];
+        place_read_split<SLOTS, SET_BITS, STATS>(db, prm, cx, bases, b0, b1, r, out, stats);
+        wave_sync();
+    }
+}
+
+template <int SLOTS, int SET_BITS, bool STATS, bool BINARY>
+__global__ __launch_bounds__(64 * WAVES_PER_BLOCK, MIN_WAVES_PER_EU) void place_wave_kernel(DbDev db, PlaceParams prm,
                                                                           const uint8_t* __restrict__ bases,
                                                                           const uint64_t* __restrict__ offsets,
                                                                           uint32_t n_reads, cls_placement* __restrict__ out,
@@ -381,7 +628,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void place_wave_kernel(DbDev 
     const uint32_t n_waves = gridDim.x * WAVES_PER_BLOCK;
     for (uint32_t r = gw; r < n_reads; r += n_waves) {
         const uint64_t b0 = offsets[r], b1 = offsets[r + 1];
-        place_read<SLOTS, SET_BITS, STATS>(db, prm, cx, bases, b0, b1, r, out, stats);
+        place_read<SLOTS, SET_BITS, STATS, BINARY>(db, prm, cx, bases, b0, b1, r, out, stats);
         wave_sync();
     }
 }
@@ -411,15 +658,26 @@ hipError_t launch_place(const DbDev& db, const PlaceParams& prm, const uint8_t* 
                         uint32_t grid_blocks, hipStream_t stream) {
     if (n_reads == 0) return hipSuccess;
     constexpr int SLOTS = 5, SET_BITS = 9;  // 320 k-mers per read; 512-entry LDS set
-    const uint32_t seq_cap = (64 * SLOTS / 2 + db.k + 15) & ~15u;
+    const uint32_t seq_cap = (2 * (64 * SLOTS / 2 + db.k) + 15) & ~15u;
     const size_t smem = (size_t)WAVES_PER_BLOCK * (seq_cap + (4u << SET_BITS) + 4u * 64 * SLOTS);
     const uint32_t ws_stride = (db.max_nonleaf_arity + 63) & ~63u;
-    if (d_stats)
-        hipLaunchKernelGGL((place_wave_kernel<SLOTS, SET_BITS, true>), dim3(grid_blocks), dim3(64 * WAVES_PER_BLOCK), smem, stream,
-                           db, prm, d_bases, d_offsets, n_reads, d_out, d_stats, seq_cap, d_ws, ws_stride);
-    else
-        hipLaunchKernelGGL((place_wave_kernel<SLOTS, SET_BITS, false>), dim3(grid_blocks), dim3(64 * WAVES_PER_BLOCK), smem, stream,
-                           db, prm, d_bases, d_offsets, n_reads, d_out, d_stats, seq_cap, d_ws, ws_stride);
+    const dim3 grid(grid_blocks), block(64 * WAVES_PER_BLOCK);
+    if (db.format == FMT_SPLIT) {
+        if (d_stats)
+            hipLaunchKernelGGL((place_split_kernel<SLOTS, SET_BITS, true>), grid, block, smem, stream, db, prm, d_bases, d_offsets,
+                               n_reads, d_out, d_stats, seq_cap);
+        else
+            hipLaunchKernelGGL((place_split_kernel<SLOTS, SET_BITS, false>), grid, block, smem, stream, db, prm, d_bases, d_offsets,
+                               n_reads, d_out, d_stats, seq_cap);
+        return hipGetLastError();
+    }
+    const bool binary = db.max_nonleaf_arity <= 2;  // no node has more than two non-LEAF children
+#define CLS_LAUNCH(ST, BI)                                                                                          \
+    hipLaunchKernelGGL((place_wave_kernel<SLOTS, SET_BITS, ST, BI>), grid, block, smem, stream, db, prm, d_bases,  \
+                       d_offsets, n_reads, d_out, d_stats, seq_cap, d_ws, ws_stride)
+    if (d_stats) { if (binary) CLS_LAUNCH(true, true); else CLS_LAUNCH(true, false); }
+    else { if (binary) CLS_LAUNCH(false, true); else CLS_LAUNCH(false, false); }
+#undef CLS_LAUNCH
     return hipGetLastError();
 }
 
