@@ -210,7 +210,7 @@ extern "C" int cls_place_batch_device(cls_db* db, const void* d_bases, const voi
     try {
         hipStream_t stream = (hipStream_t)hip_stream;
         const cls::PlaceParams prm = resolve(params);
-        const uint32_t grid = cls::place_grid_blocks(n, (uint32_t)db->n_cu, db->dev);
+        const uint32_t grid = cls::place_grid_blocks(n, (uint32_t)db->n_cu, db->dev, d_stats != nullptr);
         const uint64_t ws_words = cls::place_ws_words(db->dev, grid);
         uint32_t* ws_ptr = nullptr;
         size_t slot = 0;

@@ -196,22 +196,27 @@ int encode_db(const cls_db_desc* d, EncodedDb& E, std::string& err) {
     for (unsigned t = 0; t < nt; ++t)
         for (uint64_t j = chunk_range[t].first; j < chunk_range[t].second; ++j) kmer_off[j] = chunk_base[t] + local_off[j];
     // ---- 4b. split-tree form when the whole index allows it (see cls_device.h) -------
+    const uint64_t* d_kmer_hash = d->kmer_hash;
     E.strictly_binary = true;
     for (uint32_t r = 0; r < N; ++r)
         if (E.nodes[r].n_children != 0 && E.nodes[r].n_children != 2) { E.strictly_binary = false; break; }
     E.format = (E.strictly_binary && n_closed.load() == NK) ? FMT_SPLIT : FMT_LIST;
     if (E.format == FMT_SPLIT) {
+        // per k-mer: 2 header records + (n-1) split nodes + (n == 1 ? 0 : 0) ... see cls_device.h
         std::vector<uint64_t> rec_off(NK + 1, 0);
-        for (uint64_t j = 0; j < NK; ++j) rec_off[j + 1] = rec_off[j] + 1 + (E.postings[kmer_off[j]] & POST_LEN_MASK);
+        for (uint64_t j = 0; j < NK; ++j) {
+            const uint32_t n = E.postings[kmer_off[j]] & POST_LEN_MASK;
+            rec_off[j + 1] = rec_off[j] + SPLIT_HEADER_RECS + (n ? n - 1 : 0);
+        }
         if (rec_off[NK] >= (1ULL << 32)) { err = "split-tree postings exceed 2^32 records"; return CLS_E_BAD_DB; }
         std::vector<uint32_t> recs((rec_off[NK] + 1) * 4, 0);
         parallel_chunks(NK, nt, [&](unsigned, uint64_t lo, uint64_t hi) {
-            std::vector<uint32_t> d, stk, L, R;
+            std::vector<uint32_t> d, stk, L, R, pos, span_lo, span_hi;
             for (uint64_t j = lo; j < hi; ++j) {
                 const uint32_t* w = &E.postings[kmer_off[j]];
                 const uint32_t n = w[0] & POST_LEN_MASK;
                 const uint32_t* tip = w + POST_HEADER_WORDS;
-                const uint64_t base = rec_off[j];  // header record; tip i lives at base + 1 + i
+                const uint64_t base = rec_off[j];  // 2 header records, then the split nodes
                 d.assign(n, 0); L.assign(n, 0); R.assign(n, 0);
                 for (uint32_t i = 1; i < n; ++i) {  // depth of LCA(tip[i-1], tip[i])
                     uint32_t a = tip[i - 1];
@@ -227,17 +232,42 @@ int encode_db(const cls_db_desc* d, EncodedDb& E, std::string& err) {
                     stk.push_back(i);
                 }
                 const uint32_t root = stk.empty() ? 0 : stk.front();
+                // memory order of the split nodes: DFS pre-order, the child that parts MORE tips first
+                // (a read's walk follows the heavier side more often, so consecutive steps tend to
+                // share a 64-byte line)
+                pos.assign(n, 0); span_lo.assign(n, 0); span_hi.assign(n, 0);
+                if (root) {
+                    uint32_t next = 0;
+                    stk.clear();
+                    stk.push_back(root);
+                    span_lo[root] = 0; span_hi[root] = n;
+                    while (!stk.empty()) {
+                        const uint32_t x = stk.back(); stk.pop_back();
+                        pos[x] = next++;
+                        const uint32_t l = L[x], r = R[x];
+                        if (l) { span_lo[l] = span_lo[x]; span_hi[l] = x; }
+                        if (r) { span_lo[r] = x; span_hi[r] = span_hi[x]; }
+                        const bool left_heavy = (x - span_lo[x]) >= (span_hi[x] - x);
+                        if (left_heavy) { if (r) stk.push_back(r); if (l) stk.push_back(l); }
+                        else { if (l) stk.push_back(l); if (r) stk.push_back(r); }
+                    }
+                }
+                auto at = [&](uint32_t i) { return (uint32_t)(base + SPLIT_HEADER_RECS + pos[i]); };
                 uint32_t* h = &recs[base * 4];
                 h[0] = w[0];
-                h[1] = w[1];
-                h[2] = root ? (uint32_t)(base + 1 + root) : 0;
+                h[1] = root ? at(root) : 0;
+                h[2] = n ? tip[0] : 0;
                 h[3] = n ? tip[n - 1] : 0;
-                for (uint32_t i = 0; i < n; ++i) {
-                    uint32_t* t = &recs[(base + 1 + i) * 4];
+                h[4] = w[1];  // n_leaf_ids (statistics)
+                h[5] = (uint32_t)d_kmer_hash[j];
+                h[6] = (uint32_t)(d_kmer_hash[j] >> 32);
+                h[7] = bucket_of[j];
+                for (uint32_t i = 1; i < n; ++i) {
+                    uint32_t* t = &recs[(size_t)at(i) * 4];
                     t[0] = tip[i];
-                    t[1] = i ? tip[i - 1] : 0;
-                    t[2] = L[i] ? (uint32_t)(base + 1 + L[i]) : 0;
-                    t[3] = R[i] ? (uint32_t)(base + 1 + R[i]) : 0;
+                    t[1] = tip[i - 1];
+                    t[2] = L[i] ? at(L[i]) : 0;
+                    t[3] = R[i] ? at(R[i]) : 0;
                 }
             }
         });

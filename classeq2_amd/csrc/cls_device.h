@@ -53,15 +53,19 @@ constexpr uint32_t POST_HEADER_WORDS = 2;
 
 // ---- postings, "split-tree" form (FMT_SPLIT) ----------------------------------
 // Used when EVERY node set is closed under `parent` AND every clade has exactly
-// zero or two children.  16-byte records; a k-mer owns 1 header + n tip records:
-//   header : {n_tips | POST_HAS_ROOT | POST_CLOSED, n_leaf_ids, root split (record index, 0 = none), last tip}
-//   tip i  : {tip[i], tip[i-1], L, R}
-// tip[] ascending pre-order indices.  Position i (1 <= i < n) doubles as the node
-// of the Cartesian tree over depth(LCA(tip[i-1], tip[i])): for the tips inside one
-// clade's interval the shallowest such LCA is where the clade's two children part
-// them, so L / R (absolute record indices, 0 = none) are the splits of the left /
-// right part.  Descending one level costs ONE 16-byte read per k-mer that has tips
-// on both sides, and none otherwise.
+// zero or two children.  16-byte records; a k-mer with n tips owns 2 header
+// records + (n-1) split nodes:
+//   header 0 : {n | POST_HAS_ROOT | POST_CLOSED, root split (record index, 0 = none), first tip, last tip}
+//   header 1 : {n_leaf_ids (statistics), hash lo, hash hi, minimizer-bucket index}
+//   split i  : {tip[i], tip[i-1], L, R}            (1 <= i < n)
+// tip[] = ascending pre-order indices.  Split i is the node of the Cartesian tree
+// over depth(LCA(tip[i-1], tip[i])): for the tips inside one clade's interval the
+// shallowest such LCA is where the clade's two children part them, so L / R
+// (absolute record indices, 0 = none) are the splits of the left / right part.
+// Descending one level costs ONE 16-byte read per k-mer that has tips on both
+// sides, and none otherwise.  Split nodes are stored in DFS pre-order, heavier
+// child first, so the successive reads of one k-mer tend to share a 64-byte line.
+constexpr uint32_t SPLIT_HEADER_RECS = 2;
 struct TipRec {
     uint32_t tip;
     uint32_t tip_prev;

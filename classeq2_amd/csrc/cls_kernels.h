@@ -7,7 +7,7 @@
 namespace cls {
 
 // Workgroups to launch for `n_reads` on a device with `n_cu` compute units.
-uint32_t place_grid_blocks(uint32_t n_reads, uint32_t n_cu, const DbDev& db);
+uint32_t place_grid_blocks(uint32_t n_reads, uint32_t n_cu, const DbDev& db, bool stats);
 // u32 words of per-wave child-counter workspace the launch needs (0 for trees
 // whose nodes have at most two non-LEAF children).
 uint32_t place_ws_words(const DbDev& db, uint32_t grid_blocks);

@@ -12,6 +12,7 @@
 // Integer set membership only: no MFMA.  See DESIGN.md for the data layout and
 // the roofline accounting.
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 
 #include "cls_device.h"
 #include "cls_kernels.h"
@@ -182,6 +183,7 @@ __device__ __forceinline__ bool match_phase(const DbDev& db, const WaveCtx& cx, 
     // (forward ones first, then those of the reverse complement, kmers_map.rs:387-395) is the
     // k contiguous bytes at kmer_start(j).
     bool bad = false;
+#pragma unroll 1
     for (uint32_t i = lane; i < L; i += 64) {
         uint8_t c = bases[b0 + i];
         if (c >= 'a' && c <= 'z') c -= 32;
@@ -189,6 +191,7 @@ __device__ __forceinline__ bool match_phase(const DbDev& db, const WaveCtx& cx, 
         cx.seq[i] = c;
         cx.seq[2 * L - 1 - i] = c ^ ((c & 2) ? 0x04 : 0x15);  // A<->T, C<->G
     }
+#pragma unroll 1
     for (uint32_t i = lane; i < (1u << SET_BITS); i += 64) cx.set[i] = SET_EMPTY;
     if (__ballot(bad)) {
         put_stats(0, 0, 0, 0);  // the reference dies inside build_kmer_from_string, before any count exists
@@ -202,6 +205,7 @@ __device__ __forceinline__ bool match_phase(const DbDev& db, const WaveCtx& cx, 
     const uint8_t* seq = cx.seq;
     const uint32_t m_eff = db.m_eff;
     auto kmer_start = [&](uint32_t j) -> const uint8_t* { return seq + (j < nf ? j : L + (j - nf)); };
+#pragma unroll 1
     for (uint32_t base = 0; base < nk; base += 64) {
         const uint32_t j = base + lane;
         bool hit = false;
@@ -211,6 +215,7 @@ __device__ __forceinline__ bool match_phase(const DbDev& db, const WaveCtx& cx, 
             uint64_t h;
             hash_kmer_and_prefix(kmer_start(j), k, m_eff, h, mz);
             uint64_t idx = h & db.table_mask;
+#pragma unroll 1
             for (;;) {
                 const Slot sl = db.table[idx];
                 if (sl.loc == SLOT_EMPTY) break;
@@ -227,6 +232,7 @@ __device__ __forceinline__ bool match_phase(const DbDev& db, const WaveCtx& cx, 
             const int src = __ffsll((unsigned long long)pend) - 1;
             const uint64_t B = ((uint64_t)__shfl((uint32_t)(bk >> 32), src) << 32) | __shfl((uint32_t)bk, src);
             bool f = false;
+#pragma unroll 1
             for (uint32_t jj = lane; jj < nk; jj += 64) {
                 uint64_t hh, mm;
                 hash_kmer_and_prefix(kmer_start(jj), m_eff, m_eff, hh, mm);
@@ -239,6 +245,7 @@ __device__ __forceinline__ bool match_phase(const DbDev& db, const WaveCtx& cx, 
         uint32_t ent = SET_EMPTY;
         if (hit && ok) {  // HashSet<u64> of hashes: count each distinct hash once
             uint32_t pos = (tidx * 2654435761u) >> (32 - SET_BITS);
+#pragma unroll 1
             for (;;) {
                 const uint32_t old = atomicCAS(&cx.set[pos], SET_EMPTY, tidx);
                 if (old == SET_EMPTY) { ent = (uint32_t)(loc >> LOC_BUCKET_BITS); break; }
@@ -462,10 +469,12 @@ __device__ __forceinline__ void place_read(const DbDev db, const PlaceParams prm
 template <int SLOTS, int SET_BITS, bool STATS>
 __device__ __forceinline__ void place_read_split(const DbDev db, const PlaceParams prm, const WaveCtx cx,
                                                  const uint8_t* __restrict__ bases, uint64_t b0, uint64_t b1, uint32_t r,
-                                                 cls_placement* __restrict__ out, cls_query_stats* __restrict__ stats) {
+                                                 cls_placement* __restrict__ out, cls_query_stats* __restrict__ stats,
+                                                 uint32_t profile_stop) {
     const uint32_t lane = threadIdx.x & 63;
     uint32_t nk = 0;
     if (!match_phase<SLOTS, SET_BITS, STATS>(db, cx, bases, b0, b1, r, out, stats, nk)) return;
+    if (profile_stop == 1) { write_record(out, r, 0xFE, (int32_t)cx.ent[lane], 0, 0, 0); return; }  // profiling aid only
     const uint4* __restrict__ recs = reinterpret_cast<const uint4*>(db.postings);
     uint32_t vlo[SLOTS], vhi[SLOTS], x[SLOTS];
     uint32_t act = 0, n_m = 0, n_root = 0;
@@ -475,19 +484,13 @@ __device__ __forceinline__ void place_read_split(const DbDev db, const PlacePara
         const uint32_t j = s * 64 + lane;
         const uint32_t off = (j < nk) ? cx.ent[j] : SET_EMPTY;
         const bool is_new = off != SET_EMPTY;
-        bool has_root = false;
-        vlo[s] = vhi[s] = x[s] = 0;
-        if (is_new) {
-            const uint4 hd = recs[off];  // {n | flags, n_leaf_ids, root split, last tip}
-            if (STATS) leafp += hd.y;
-            has_root = (hd.x & POST_HAS_ROOT) != 0;
-            if (has_root && (hd.x & POST_LEN_MASK)) {
-                vlo[s] = recs[off + 1].x;
-                vhi[s] = hd.w;
-                x[s] = hd.z;
-                act |= 1u << s;
-            }
-        }
+        const uint4 hd = recs[is_new ? off : 0u];  // {n | flags, root split, first tip, last tip}
+        if (STATS && is_new) leafp += recs[off + 1].x;
+        const bool has_root = is_new && (hd.x & POST_HAS_ROOT) != 0;
+        vlo[s] = hd.z;
+        vhi[s] = hd.w;
+        x[s] = hd.y;
+        if (has_root && (hd.x & POST_LEN_MASK)) act |= 1u << s;
         n_m += popc64(__ballot(is_new));
         n_root += popc64(__ballot(is_new && has_root));
     }
@@ -500,6 +503,7 @@ __device__ __forceinline__ void place_read_split(const DbDev db, const PlacePara
             s[2] = leafp;
         }
     }
+    if (profile_stop == 2) { write_record(out, r, 0xFE, (int32_t)(vlo[0] + vhi[1] + x[2] + act), 0, 0, 0); return; }
     // ---- B. thresholds (as in place_read) ------------------------------------------------------
     if (n_m == 0) { write_record(out, r, CLS_UNCLASSIFIABLE_NO_MATCH, 0, 0, 0, 0); return; }
     if (n_root == 0) { write_record(out, r, CLS_UNCLASSIFIABLE_NO_ROOT, 0, 0, 0, 0); return; }
@@ -566,22 +570,30 @@ __device__ __forceinline__ void place_read_split(const DbDev db, const PlacePara
             return;
         }
         prow = crow;
-        // narrow to the chosen clade: ONE 16-byte read for a k-mer with tips on both sides, none otherwise
-        if (best == 0) {
+        // narrow to the chosen clade: ONE 16-byte read for a k-mer with tips on both sides, none
+        // otherwise.  The reads of a lane's SLOTS k-mers are issued back to back (record 0 stands in
+        // for "no read") so that their HBM round trips overlap.
+        uint4 t[SLOTS];
+        uint32_t need = 0;
 #pragma unroll
-            for (int s = 0; s < SLOTS; ++s) {
-                if (!((act >> s) & 1u)) continue;
-                if (vlo[s] >= a1 || vlo[s] == a0) { act &= ~(1u << s); continue; }  // nothing strictly below clade a
-                if (vhi[s] >= a1) { const uint4 t = recs[x[s]]; vhi[s] = t.y; x[s] = t.z; }
-            }
-        } else {
+        for (int s = 0; s < SLOTS; ++s) {
+            const bool on = (act >> s) & 1u;
+            const bool gone = best == 0 ? (vlo[s] >= a1 || vlo[s] == a0) : (vhi[s] < a1);
+            if (on && gone) act &= ~(1u << s);
+            const bool straddles = on && !gone && (best == 0 ? vhi[s] >= a1 : vlo[s] < a1);
+            if (straddles) need |= 1u << s;
+            t[s] = recs[straddles ? x[s] : 0u];
+        }
 #pragma unroll
-            for (int s = 0; s < SLOTS; ++s) {
-                if (!((act >> s) & 1u)) continue;
-                if (vhi[s] < a1) { act &= ~(1u << s); continue; }
-                if (vlo[s] < a1) { const uint4 t = recs[x[s]]; vlo[s] = t.x; x[s] = t.w; }
-                if (vlo[s] == a1) act &= ~(1u << s);  // the clade itself is the tip: nothing below it
-            }
+        for (int s = 0; s < SLOTS; ++s) {
+            if (!((need >> s) & 1u)) continue;
+            if (best == 0) { vhi[s] = t[s].y; x[s] = t[s].z; }
+            else { vlo[s] = t[s].x; x[s] = t[s].w; }
+        }
+        if (best != 0) {
+#pragma unroll
+            for (int s = 0; s < SLOTS; ++s)
+                if (((act >> s) & 1u) && vlo[s] == a1) act &= ~(1u << s);  // the clade itself is the tip: nothing below it
         }
     }
 }
@@ -589,7 +601,7 @@ __device__ __forceinline__ void place_read_split(const DbDev db, const PlacePara
 template <int SLOTS, int SET_BITS, bool STATS>
 __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, MIN_WAVES_PER_EU) void place_split_kernel(
     DbDev db, PlaceParams prm, const uint8_t* __restrict__ bases, const uint64_t* __restrict__ offsets, uint32_t n_reads,
-    cls_placement* __restrict__ out, cls_query_stats* __restrict__ stats, uint32_t seq_cap) {
+    cls_placement* __restrict__ out, cls_query_stats* __restrict__ stats, uint32_t seq_cap, uint32_t profile_stop) {
     extern __shared__ __align__(16) uint8_t smem[];
     const uint32_t wave = threadIdx.x >> 6;
     const uint32_t per_wave = seq_cap + (4u << SET_BITS) + 4u * 64 * SLOTS;
@@ -602,7 +614,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, MIN_WAVES_PER_EU) void place_
     const uint32_t n_waves = gridDim.x * WAVES_PER_BLOCK;
     for (uint32_t r = gw; r < n_reads; r += n_waves) {
         const uint64_t b0 = offsets[r], b1 = offsets[r + 1];
-        place_read_split<SLOTS, SET_BITS, STATS>(db, prm, cx, bases, b0, b1, r, out, stats);
+        place_read_split<SLOTS, SET_BITS, STATS>(db, prm, cx, bases, b0, b1, r, out, stats, profile_stop);
         wave_sync();
     }
 }
@@ -635,17 +647,40 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, MIN_WAVES_PER_EU) void place_
 
 }  // namespace
 
+namespace {
+constexpr int K_SLOTS = 5, K_SET_BITS = 9;  // 320 k-mers per read; 512-entry LDS set
+
+uint32_t seq_cap_of(const DbDev& db) { return (2 * (64 * K_SLOTS / 2 + db.k) + 15) & ~15u; }
+size_t smem_of(const DbDev& db) { return (size_t)WAVES_PER_BLOCK * (seq_cap_of(db) + (4u << K_SET_BITS) + 4u * 64 * K_SLOTS); }
+
+const void* kernel_of(const DbDev& db, bool stats) {
+    if (db.format == FMT_SPLIT)
+        return stats ? (const void*)place_split_kernel<K_SLOTS, K_SET_BITS, true> : (const void*)place_split_kernel<K_SLOTS, K_SET_BITS, false>;
+    const bool binary = db.max_nonleaf_arity <= 2;  // no node has more than two non-LEAF children
+    if (stats) return binary ? (const void*)place_wave_kernel<K_SLOTS, K_SET_BITS, true, true> : (const void*)place_wave_kernel<K_SLOTS, K_SET_BITS, true, false>;
+    return binary ? (const void*)place_wave_kernel<K_SLOTS, K_SET_BITS, false, true> : (const void*)place_wave_kernel<K_SLOTS, K_SET_BITS, false, false>;
+}
+}  // namespace
+
 uint32_t place_ws_words(const DbDev& db, uint32_t grid_blocks) {
-    if (db.max_nonleaf_arity <= 2) return 0;
+    if (db.format == FMT_SPLIT || db.max_nonleaf_arity <= 2) return 0;
     return grid_blocks * WAVES_PER_BLOCK * 2 * ((db.max_nonleaf_arity + 63) & ~63u);
 }
 
-uint32_t place_grid_blocks(uint32_t n_reads, uint32_t n_cu, const DbDev& db) {
+uint32_t place_grid_blocks(uint32_t n_reads, uint32_t n_cu, const DbDev& db, bool stats) {
     uint32_t want = (n_reads + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
-    uint32_t cap = n_cu * 8;  // 8 blocks x 4 waves = 32 waves per CU
-    if (db.max_nonleaf_arity > 2) {
+    // persistent-style grid: exactly the blocks that are resident at once (every wave then strides
+    // over the reads); CLS_BLOCKS_PER_CU overrides it for tuning experiments
+    static const int forced = [] { const char* e = getenv("CLS_BLOCKS_PER_CU"); return e ? atoi(e) : 0; }();
+    int per_cu = forced;
+    if (per_cu <= 0) {
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel_of(db, stats), 64 * WAVES_PER_BLOCK, smem_of(db)) != hipSuccess || per_cu <= 0)
+            per_cu = 2;
+    }
+    uint32_t cap = n_cu * (uint32_t)per_cu;
+    if (place_ws_words(db, 1)) {
         // bound the per-wave child-counter workspace to 256 MiB
-        uint64_t per_block = (uint64_t)WAVES_PER_BLOCK * 2 * ((db.max_nonleaf_arity + 63) & ~63u) * 4;
+        uint64_t per_block = (uint64_t)place_ws_words(db, 1) * 4;
         uint64_t fit = (256ull << 20) / per_block;
         if (fit < 1) fit = 1;
         if (cap > fit) cap = (uint32_t)fit;
@@ -657,18 +692,21 @@ hipError_t launch_place(const DbDev& db, const PlaceParams& prm, const uint8_t* 
                         uint32_t n_reads, cls_placement* d_out, cls_query_stats* d_stats, uint32_t* d_ws,
                         uint32_t grid_blocks, hipStream_t stream) {
     if (n_reads == 0) return hipSuccess;
-    constexpr int SLOTS = 5, SET_BITS = 9;  // 320 k-mers per read; 512-entry LDS set
-    const uint32_t seq_cap = (2 * (64 * SLOTS / 2 + db.k) + 15) & ~15u;
-    const size_t smem = (size_t)WAVES_PER_BLOCK * (seq_cap + (4u << SET_BITS) + 4u * 64 * SLOTS);
+    constexpr int SLOTS = K_SLOTS, SET_BITS = K_SET_BITS;
+    const uint32_t seq_cap = seq_cap_of(db);
+    const size_t smem = smem_of(db);
     const uint32_t ws_stride = (db.max_nonleaf_arity + 63) & ~63u;
     const dim3 grid(grid_blocks), block(64 * WAVES_PER_BLOCK);
     if (db.format == FMT_SPLIT) {
+        // CLS_PROFILE_STOP=1|2 truncates the kernel after the match / state-init phase (timing
+        // breakdowns only: the records it writes are meaningless)
+        static const uint32_t profile_stop = [] { const char* e = getenv("CLS_PROFILE_STOP"); return e ? (uint32_t)atoi(e) : 0u; }();
         if (d_stats)
             hipLaunchKernelGGL((place_split_kernel<SLOTS, SET_BITS, true>), grid, block, smem, stream, db, prm, d_bases, d_offsets,
-                               n_reads, d_out, d_stats, seq_cap);
+                               n_reads, d_out, d_stats, seq_cap, profile_stop);
         else
             hipLaunchKernelGGL((place_split_kernel<SLOTS, SET_BITS, false>), grid, block, smem, stream, db, prm, d_bases, d_offsets,
-                               n_reads, d_out, d_stats, seq_cap);
+                               n_reads, d_out, d_stats, seq_cap, profile_stop);
         return hipGetLastError();
     }
     const bool binary = db.max_nonleaf_arity <= 2;  // no node has more than two non-LEAF children
