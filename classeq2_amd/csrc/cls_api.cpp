@@ -63,7 +63,7 @@ struct cls_db {
     void* d_postings = nullptr;
     void* d_bucket_key = nullptr;
     std::mutex ws_mu;
-    std::vector<Workspace> ws;  // child-counter workspaces (polytomy trees only)
+    std::vector<Workspace> ws;  // per-call scratch (class lists, child counters), recycled once their launch has finished
 };
 
 extern "C" const char* cls_last_error(void) { return g_err.c_str(); }
@@ -184,7 +184,7 @@ extern "C" int cls_db_info_get(const cls_db* db, cls_db_info* info) {
     return CLS_OK;
 }
 
-// Take (or grow) a child-counter workspace whose previous user has finished.
+// Take (or add) a scratch workspace whose previous user has finished.
 static int acquire_ws(cls_db* db, uint64_t words, size_t* slot) {
     std::lock_guard<std::mutex> g(db->ws_mu);
     for (size_t i = 0; i < db->ws.size(); ++i) {
@@ -193,7 +193,7 @@ static int acquire_ws(cls_db* db, uint64_t words, size_t* slot) {
         if (!w.busy && w.words >= words) { w.busy = true; *slot = i; return CLS_OK; }
     }
     Workspace w;
-    if (hipMalloc((void**)&w.ptr, words * 4) != hipSuccess) return fail(CLS_E_NOMEM, "child-counter workspace allocation failed");
+    if (hipMalloc((void**)&w.ptr, words * 4) != hipSuccess) return fail(CLS_E_NOMEM, "scratch workspace allocation failed");
     if (hipEventCreateWithFlags(&w.done, hipEventDisableTiming) != hipSuccess) { (void)hipFree(w.ptr); return fail(CLS_E_HIP, "hipEventCreate failed"); }
     w.words = words;
     w.busy = true;
@@ -210,18 +210,13 @@ extern "C" int cls_place_batch_device(cls_db* db, const void* d_bases, const voi
     try {
         hipStream_t stream = (hipStream_t)hip_stream;
         const cls::PlaceParams prm = resolve(params);
-        const uint32_t grid = cls::place_grid_blocks(n, (uint32_t)db->n_cu, db->dev, d_stats != nullptr);
-        const uint64_t ws_words = cls::place_ws_words(db->dev, grid);
-        uint32_t* ws_ptr = nullptr;
+        const cls::PlacePlan plan = cls::plan_place(db->dev, n, (uint32_t)db->n_cu, d_stats != nullptr);
         size_t slot = 0;
-        if (ws_words) {
-            int rc = acquire_ws(db, ws_words, &slot);
-            if (rc != CLS_OK) return rc;
-            ws_ptr = db->ws[slot].ptr;
-        }
-        hipError_t e = cls::launch_place(db->dev, prm, (const uint8_t*)d_bases, (const uint64_t*)d_offsets, n,
-                                         (cls_placement*)d_out, (cls_query_stats*)d_stats, ws_ptr, grid, stream);
-        if (ws_words) {
+        int rc = acquire_ws(db, (plan.ws_bytes + 3) / 4, &slot);
+        if (rc != CLS_OK) return rc;
+        hipError_t e = cls::launch_place(db->dev, prm, plan, (const uint8_t*)d_bases, (const uint64_t*)d_offsets, n,
+                                         (cls_placement*)d_out, (cls_query_stats*)d_stats, db->ws[slot].ptr, stream);
+        {
             std::lock_guard<std::mutex> g(db->ws_mu);
             if (hipEventRecord(db->ws[slot].done, stream) != hipSuccess) db->ws[slot].busy = false;
         }

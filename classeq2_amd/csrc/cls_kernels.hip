@@ -14,6 +14,9 @@
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
 
+#include <algorithm>
+#include <type_traits>
+
 #include "cls_device.h"
 #include "cls_kernels.h"
 #include "cls_murmur.h"
@@ -73,6 +76,27 @@ __device__ __forceinline__ void multi_lower_bound(const uint32_t* __restrict__ p
 #pragma unroll
     for (int s = 0; s < SLOTS; ++s)
         if ((need >> s) & 1u) { if (LO_SIDE) hi[s] = other[s]; else lo[s] = other[s]; }
+}
+
+// the same over groups of at most 5 slots (bounds the registers of wide kernels)
+template <int SLOTS, bool LO_SIDE>
+__device__ __forceinline__ void multi_lower_bound_grouped(const uint32_t* __restrict__ post, uint32_t (&lo)[SLOTS],
+                                                          uint32_t (&hi)[SLOTS], uint32_t key, uint32_t need) {
+    if constexpr (SLOTS <= 5) {
+        multi_lower_bound<SLOTS, LO_SIDE>(post, lo, hi, key, need);
+    } else {
+        constexpr int G = 4;
+        static_assert(SLOTS % G == 0, "SLOTS must be a multiple of 4 above 5");
+#pragma unroll
+        for (int g0 = 0; g0 < SLOTS; g0 += G) {
+            uint32_t l[G], h[G];
+#pragma unroll
+            for (int i = 0; i < G; ++i) { l[i] = lo[g0 + i]; h[i] = hi[g0 + i]; }
+            multi_lower_bound<G, LO_SIDE>(post, l, h, key, (need >> g0) & ((1u << G) - 1));
+#pragma unroll
+            for (int i = 0; i < G; ++i) { lo[g0 + i] = l[i]; hi[g0 + i] = h[i]; }
+        }
+    }
 }
 
 // rare, kept out of line: the interval has stored elements on both sides of it
@@ -448,7 +472,7 @@ __device__ __forceinline__ void place_read(const DbDev db, const PlaceParams prm
             if (vhi[s] >= n1) need_hi |= 1u << s;
         }
         if (__ballot(need_lo != 0)) {
-            multi_lower_bound<SLOTS, true>(post, lo, hi, n0, need_lo);  // < hi because vhi >= n0
+            multi_lower_bound_grouped<SLOTS, true>(post, lo, hi, n0, need_lo);  // < hi because vhi >= n0
 #pragma unroll
             for (int s = 0; s < SLOTS; ++s) if (need_lo & (1u << s)) vlo[s] = post[lo[s]];
 #pragma unroll
@@ -456,7 +480,7 @@ __device__ __forceinline__ void place_read(const DbDev db, const PlaceParams prm
                 if ((need_lo & (1u << s)) && vlo[s] >= n1) { act &= ~(1u << s); need_hi &= ~(1u << s); }
         }
         if (__ballot(need_hi != 0)) {
-            multi_lower_bound<SLOTS, false>(post, lo, hi, n1, need_hi);  // > lo because vlo < n1
+            multi_lower_bound_grouped<SLOTS, false>(post, lo, hi, n1, need_hi);  // > lo because vlo < n1
 #pragma unroll
             for (int s = 0; s < SLOTS; ++s) if (need_hi & (1u << s)) vhi[s] = post[hi[s] - 1];
         }
@@ -573,22 +597,29 @@ __device__ __forceinline__ void place_read_split(const DbDev db, const PlacePara
         // narrow to the chosen clade: ONE 16-byte read for a k-mer with tips on both sides, none
         // otherwise.  The reads of a lane's SLOTS k-mers are issued back to back (record 0 stands in
         // for "no read") so that their HBM round trips overlap.
-        uint4 t[SLOTS];
-        uint32_t need = 0;
+        constexpr int G = SLOTS <= 5 ? SLOTS : 4;  // reads in flight per lane
 #pragma unroll
-        for (int s = 0; s < SLOTS; ++s) {
-            const bool on = (act >> s) & 1u;
-            const bool gone = best == 0 ? (vlo[s] >= a1 || vlo[s] == a0) : (vhi[s] < a1);
-            if (on && gone) act &= ~(1u << s);
-            const bool straddles = on && !gone && (best == 0 ? vhi[s] >= a1 : vlo[s] < a1);
-            if (straddles) need |= 1u << s;
-            t[s] = recs[straddles ? x[s] : 0u];
-        }
+        for (int g0 = 0; g0 < SLOTS; g0 += G) {
+            uint4 t[G];
+            uint32_t need = 0;
 #pragma unroll
-        for (int s = 0; s < SLOTS; ++s) {
-            if (!((need >> s) & 1u)) continue;
-            if (best == 0) { vhi[s] = t[s].y; x[s] = t[s].z; }
-            else { vlo[s] = t[s].x; x[s] = t[s].w; }
+            for (int i = 0; i < G; ++i) {
+                const int s = g0 + i;
+                if (s >= SLOTS) { t[i] = uint4{0, 0, 0, 0}; continue; }
+                const bool on = (act >> s) & 1u;
+                const bool gone = best == 0 ? (vlo[s] >= a1 || vlo[s] == a0) : (vhi[s] < a1);
+                if (on && gone) act &= ~(1u << s);
+                const bool straddles = on && !gone && (best == 0 ? vhi[s] >= a1 : vlo[s] < a1);
+                if (straddles) need |= 1u << i;
+                t[i] = recs[straddles ? x[s] : 0u];
+            }
+#pragma unroll
+            for (int i = 0; i < G; ++i) {
+                const int s = g0 + i;
+                if (s >= SLOTS || !((need >> i) & 1u)) continue;
+                if (best == 0) { vhi[s] = t[i].y; x[s] = t[i].z; }
+                else { vlo[s] = t[i].x; x[s] = t[i].w; }
+            }
         }
         if (best != 0) {
 #pragma unroll
@@ -600,7 +631,8 @@ __device__ __forceinline__ void place_read_split(const DbDev db, const PlacePara
 
 template <int SLOTS, int SET_BITS, bool STATS>
 __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, MIN_WAVES_PER_EU) void place_split_kernel(
-    DbDev db, PlaceParams prm, const uint8_t* __restrict__ bases, const uint64_t* __restrict__ offsets, uint32_t n_reads,
+    DbDev db, PlaceParams prm, const uint8_t* __restrict__ bases, const uint64_t* __restrict__ offsets,
+    const uint32_t* __restrict__ list, const uint32_t* __restrict__ list_len,
     cls_placement* __restrict__ out, cls_query_stats* __restrict__ stats, uint32_t seq_cap, uint32_t profile_stop) {
     extern __shared__ __align__(16) uint8_t smem[];
     const uint32_t wave = threadIdx.x >> 6;
@@ -612,7 +644,9 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, MIN_WAVES_PER_EU) void place_
     cx.cnt = cx.only = nullptr;
     const uint32_t gw = blockIdx.x * WAVES_PER_BLOCK + wave;
     const uint32_t n_waves = gridDim.x * WAVES_PER_BLOCK;
-    for (uint32_t r = gw; r < n_reads; r += n_waves) {
+    const uint32_t n_list = *list_len;
+    for (uint32_t i = gw; i < n_list; i += n_waves) {
+        const uint32_t r = list[i];
         const uint64_t b0 = offsets[r], b1 = offsets[r + 1];
         place_read_split<SLOTS, SET_BITS, STATS>(db, prm, cx, bases, b0, b1, r, out, stats, profile_stop);
         wave_sync();
@@ -623,7 +657,9 @@ template <int SLOTS, int SET_BITS, bool STATS, bool BINARY>
 __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, MIN_WAVES_PER_EU) void place_wave_kernel(DbDev db, PlaceParams prm,
                                                                           const uint8_t* __restrict__ bases,
                                                                           const uint64_t* __restrict__ offsets,
-                                                                          uint32_t n_reads, cls_placement* __restrict__ out,
+                                                                          const uint32_t* __restrict__ list,
+                                                                          const uint32_t* __restrict__ list_len,
+                                                                          cls_placement* __restrict__ out,
                                                                           cls_query_stats* __restrict__ stats,
                                                                           uint32_t seq_cap, uint32_t* __restrict__ child_ws,
                                                                           uint32_t ws_stride) {
@@ -638,84 +674,146 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, MIN_WAVES_PER_EU) void place_
     cx.cnt = child_ws ? child_ws + (size_t)gw * 2 * ws_stride : nullptr;
     cx.only = child_ws ? cx.cnt + ws_stride : nullptr;
     const uint32_t n_waves = gridDim.x * WAVES_PER_BLOCK;
-    for (uint32_t r = gw; r < n_reads; r += n_waves) {
+    const uint32_t n_list = *list_len;
+    for (uint32_t i = gw; i < n_list; i += n_waves) {
+        const uint32_t r = list[i];
         const uint64_t b0 = offsets[r], b1 = offsets[r + 1];
         place_read<SLOTS, SET_BITS, STATS, BINARY>(db, prm, cx, bases, b0, b1, r, out, stats);
         wave_sync();
     }
 }
 
+// ---- read-length classes ----------------------------------------------------------------------
+// One thread per read: reads are binned by their k-mer count into the kernel wide enough for
+// them (class lists in device memory; nothing returns to the host).  Reads no kernel can hold
+// get their record here.
+__global__ void classify_kernel(const uint64_t* __restrict__ offsets, uint32_t n_reads, uint32_t k, uint32_t cap0,
+                                uint32_t cap1, uint32_t* __restrict__ list0, uint32_t* __restrict__ list1,
+                                uint32_t* __restrict__ counts, cls_placement* __restrict__ out,
+                                cls_query_stats* __restrict__ stats) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    int cls_id = -1;
+    if (r < n_reads) {
+        const uint64_t L = offsets[r + 1] - offsets[r];
+        const uint64_t nk = L < k ? 0 : 2 * (L - k + 1);
+        if (nk <= cap0) cls_id = 0;  // includes L < k: the kernel reports CLS_ERR_TOO_FEW_KMERS
+        else if (nk <= cap1) cls_id = 1;
+        else {
+            uint64_t* o = reinterpret_cast<uint64_t*>(out + r);
+            o[0] = CLS_ERR_READ_TOO_LONG; o[1] = 0; o[2] = 0;
+            if (stats) {
+                uint64_t* st = reinterpret_cast<uint64_t*>(stats + r);
+                st[0] = nk > 0xFFFFFFFFull ? 0xFFFFFFFFull : nk; st[1] = 0; st[2] = 0;
+            }
+        }
+    }
+    const uint32_t lane = threadIdx.x & 63;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        const uint64_t m = __ballot(cls_id == c);
+        if (!m) continue;
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(&counts[c], (uint32_t)__popcll(m));
+        base = __shfl(base, 0);
+        if (cls_id == c) (c ? list1 : list0)[base + __popcll(m & ((1ull << lane) - 1))] = r;
+    }
+}
+
 }  // namespace
 
 namespace {
-constexpr int K_SLOTS = 5, K_SET_BITS = 9;  // 320 k-mers per read; 512-entry LDS set
+constexpr int N_CLASSES = 2;
+constexpr int CLS_SLOTS[N_CLASSES] = {5, 16};      // k-mers per read: 320 / 1024
+constexpr int CLS_SET_BITS[N_CLASSES] = {9, 11};   // LDS distinct-hit set: 512 / 2048 entries
 
-uint32_t seq_cap_of(const DbDev& db) { return (2 * (64 * K_SLOTS / 2 + db.k) + 15) & ~15u; }
-size_t smem_of(const DbDev& db) { return (size_t)WAVES_PER_BLOCK * (seq_cap_of(db) + (4u << K_SET_BITS) + 4u * 64 * K_SLOTS); }
+uint32_t seq_cap_of(const DbDev& db, int c) { return (2 * (64 * CLS_SLOTS[c] / 2 + db.k) + 15) & ~15u; }
+size_t smem_of(const DbDev& db, int c) {
+    return (size_t)WAVES_PER_BLOCK * (seq_cap_of(db, c) + (4u << CLS_SET_BITS[c]) + 4u * 64 * CLS_SLOTS[c]);
+}
 
-const void* kernel_of(const DbDev& db, bool stats) {
+template <int SLOTS, int SET_BITS>
+const void* kernel_of_t(const DbDev& db, bool stats) {
     if (db.format == FMT_SPLIT)
-        return stats ? (const void*)place_split_kernel<K_SLOTS, K_SET_BITS, true> : (const void*)place_split_kernel<K_SLOTS, K_SET_BITS, false>;
+        return stats ? (const void*)place_split_kernel<SLOTS, SET_BITS, true> : (const void*)place_split_kernel<SLOTS, SET_BITS, false>;
     const bool binary = db.max_nonleaf_arity <= 2;  // no node has more than two non-LEAF children
-    if (stats) return binary ? (const void*)place_wave_kernel<K_SLOTS, K_SET_BITS, true, true> : (const void*)place_wave_kernel<K_SLOTS, K_SET_BITS, true, false>;
-    return binary ? (const void*)place_wave_kernel<K_SLOTS, K_SET_BITS, false, true> : (const void*)place_wave_kernel<K_SLOTS, K_SET_BITS, false, false>;
+    if (stats) return binary ? (const void*)place_wave_kernel<SLOTS, SET_BITS, true, true> : (const void*)place_wave_kernel<SLOTS, SET_BITS, true, false>;
+    return binary ? (const void*)place_wave_kernel<SLOTS, SET_BITS, false, true> : (const void*)place_wave_kernel<SLOTS, SET_BITS, false, false>;
+}
+const void* kernel_of(const DbDev& db, int c, bool stats) {
+    return c == 0 ? kernel_of_t<CLS_SLOTS[0], CLS_SET_BITS[0]>(db, stats) : kernel_of_t<CLS_SLOTS[1], CLS_SET_BITS[1]>(db, stats);
+}
+
+uint32_t child_ws_stride(const DbDev& db) {
+    return (db.format == FMT_SPLIT || db.max_nonleaf_arity <= 2) ? 0u : ((db.max_nonleaf_arity + 63) & ~63u);
 }
 }  // namespace
 
-uint32_t place_ws_words(const DbDev& db, uint32_t grid_blocks) {
-    if (db.format == FMT_SPLIT || db.max_nonleaf_arity <= 2) return 0;
-    return grid_blocks * WAVES_PER_BLOCK * 2 * ((db.max_nonleaf_arity + 63) & ~63u);
-}
-
-uint32_t place_grid_blocks(uint32_t n_reads, uint32_t n_cu, const DbDev& db, bool stats) {
-    uint32_t want = (n_reads + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
-    // persistent-style grid: exactly the blocks that are resident at once (every wave then strides
-    // over the reads); CLS_BLOCKS_PER_CU overrides it for tuning experiments
+PlacePlan plan_place(const DbDev& db, uint32_t n_reads, uint32_t n_cu, bool stats) {
+    PlacePlan p{};
+    // persistent-style grids: exactly the blocks that are resident at once (every wave then strides
+    // over its class list); CLS_BLOCKS_PER_CU overrides it for tuning experiments
     static const int forced = [] { const char* e = getenv("CLS_BLOCKS_PER_CU"); return e ? atoi(e) : 0; }();
-    int per_cu = forced;
-    if (per_cu <= 0) {
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel_of(db, stats), 64 * WAVES_PER_BLOCK, smem_of(db)) != hipSuccess || per_cu <= 0)
-            per_cu = 2;
+    const uint32_t want = (n_reads + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
+    uint64_t child_words = 0;
+    for (int c = 0; c < N_CLASSES; ++c) {
+        int per_cu = forced;
+        if (per_cu <= 0 &&
+            (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel_of(db, c, stats), 64 * WAVES_PER_BLOCK, smem_of(db, c)) != hipSuccess || per_cu <= 0))
+            per_cu = 1;
+        uint32_t cap = n_cu * (uint32_t)per_cu;
+        if (child_ws_stride(db)) {  // bound the per-wave child-counter workspace to 128 MiB per class
+            const uint64_t per_block = (uint64_t)WAVES_PER_BLOCK * 2 * child_ws_stride(db) * 4;
+            const uint64_t fit = std::max<uint64_t>(1, (128ull << 20) / per_block);
+            if (cap > fit) cap = (uint32_t)fit;
+        }
+        p.grid[c] = want < cap ? (want ? want : 1) : cap;
+        child_words = std::max<uint64_t>(child_words, (uint64_t)p.grid[c] * WAVES_PER_BLOCK * 2 * child_ws_stride(db));
     }
-    uint32_t cap = n_cu * (uint32_t)per_cu;
-    if (place_ws_words(db, 1)) {
-        // bound the per-wave child-counter workspace to 256 MiB
-        uint64_t per_block = (uint64_t)place_ws_words(db, 1) * 4;
-        uint64_t fit = (256ull << 20) / per_block;
-        if (fit < 1) fit = 1;
-        if (cap > fit) cap = (uint32_t)fit;
-    }
-    return want < cap ? (want ? want : 1) : cap;
+    // workspace: [counts: 16 words][list0: n][list1: n][child counters]
+    p.child_off_words = 16 + 2 * (uint64_t)n_reads;
+    p.ws_bytes = (p.child_off_words + child_words) * 4;
+    return p;
 }
 
-hipError_t launch_place(const DbDev& db, const PlaceParams& prm, const uint8_t* d_bases, const uint64_t* d_offsets,
-                        uint32_t n_reads, cls_placement* d_out, cls_query_stats* d_stats, uint32_t* d_ws,
-                        uint32_t grid_blocks, hipStream_t stream) {
+hipError_t launch_place(const DbDev& db, const PlaceParams& prm, const PlacePlan& plan, const uint8_t* d_bases,
+                        const uint64_t* d_offsets, uint32_t n_reads, cls_placement* d_out, cls_query_stats* d_stats,
+                        uint32_t* d_ws, hipStream_t stream) {
     if (n_reads == 0) return hipSuccess;
-    constexpr int SLOTS = K_SLOTS, SET_BITS = K_SET_BITS;
-    const uint32_t seq_cap = seq_cap_of(db);
-    const size_t smem = smem_of(db);
-    const uint32_t ws_stride = (db.max_nonleaf_arity + 63) & ~63u;
-    const dim3 grid(grid_blocks), block(64 * WAVES_PER_BLOCK);
-    if (db.format == FMT_SPLIT) {
-        // CLS_PROFILE_STOP=1|2 truncates the kernel after the match / state-init phase (timing
-        // breakdowns only: the records it writes are meaningless)
-        static const uint32_t profile_stop = [] { const char* e = getenv("CLS_PROFILE_STOP"); return e ? (uint32_t)atoi(e) : 0u; }();
-        if (d_stats)
-            hipLaunchKernelGGL((place_split_kernel<SLOTS, SET_BITS, true>), grid, block, smem, stream, db, prm, d_bases, d_offsets,
-                               n_reads, d_out, d_stats, seq_cap, profile_stop);
-        else
-            hipLaunchKernelGGL((place_split_kernel<SLOTS, SET_BITS, false>), grid, block, smem, stream, db, prm, d_bases, d_offsets,
-                               n_reads, d_out, d_stats, seq_cap, profile_stop);
-        return hipGetLastError();
-    }
-    const bool binary = db.max_nonleaf_arity <= 2;  // no node has more than two non-LEAF children
+    uint32_t* counts = d_ws;
+    uint32_t* lists[N_CLASSES] = {d_ws + 16, d_ws + 16 + n_reads};
+    uint32_t* child_ws = child_ws_stride(db) ? d_ws + plan.child_off_words : nullptr;
+    hipError_t e = hipMemsetAsync(counts, 0, 64, stream);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(classify_kernel, dim3((n_reads + 255) / 256), dim3(256), 0, stream, d_offsets, n_reads, db.k,
+                       (uint32_t)(64 * CLS_SLOTS[0]), (uint32_t)(64 * CLS_SLOTS[1]), lists[0], lists[1], counts, d_out, d_stats);
+    // CLS_PROFILE_STOP=1|2 truncates the split kernel after the match / state-init phase (timing
+    // breakdowns only: the records it then writes are meaningless)
+    static const uint32_t profile_stop = [] { const char* e = getenv("CLS_PROFILE_STOP"); return e ? (uint32_t)atoi(e) : 0u; }();
+    const uint32_t ws_stride = child_ws_stride(db);
+    const bool st = d_stats != nullptr;
+    const bool binary = db.max_nonleaf_arity <= 2;
+    auto launch_class = [&](auto slots_c, auto bits_c, int c) {
+        constexpr int SLOTS = decltype(slots_c)::value, SET_BITS = decltype(bits_c)::value;
+        const dim3 grid(plan.grid[c]), block(64 * WAVES_PER_BLOCK);
+        const uint32_t seq_cap = seq_cap_of(db, c);
+        const size_t smem = smem_of(db, c);
+        if (db.format == FMT_SPLIT) {
+            if (st) hipLaunchKernelGGL((place_split_kernel<SLOTS, SET_BITS, true>), grid, block, smem, stream, db, prm, d_bases, d_offsets,
+                                       lists[c], counts + c, d_out, d_stats, seq_cap, profile_stop);
+            else hipLaunchKernelGGL((place_split_kernel<SLOTS, SET_BITS, false>), grid, block, smem, stream, db, prm, d_bases, d_offsets,
+                                    lists[c], counts + c, d_out, d_stats, seq_cap, profile_stop);
+            return;
+        }
 #define CLS_LAUNCH(ST, BI)                                                                                          \
     hipLaunchKernelGGL((place_wave_kernel<SLOTS, SET_BITS, ST, BI>), grid, block, smem, stream, db, prm, d_bases,  \
-                       d_offsets, n_reads, d_out, d_stats, seq_cap, d_ws, ws_stride)
-    if (d_stats) { if (binary) CLS_LAUNCH(true, true); else CLS_LAUNCH(true, false); }
-    else { if (binary) CLS_LAUNCH(false, true); else CLS_LAUNCH(false, false); }
+                       d_offsets, lists[c], counts + c, d_out, d_stats, seq_cap, child_ws, ws_stride)
+        if (st) { if (binary) CLS_LAUNCH(true, true); else CLS_LAUNCH(true, false); }
+        else { if (binary) CLS_LAUNCH(false, true); else CLS_LAUNCH(false, false); }
 #undef CLS_LAUNCH
+    };
+    launch_class(std::integral_constant<int, CLS_SLOTS[0]>{}, std::integral_constant<int, CLS_SET_BITS[0]>{}, 0);
+    if (hipGetLastError() != hipSuccess) return hipErrorLaunchFailure;
+    launch_class(std::integral_constant<int, CLS_SLOTS[1]>{}, std::integral_constant<int, CLS_SET_BITS[1]>{}, 1);
     return hipGetLastError();
 }
 

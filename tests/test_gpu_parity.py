@@ -72,12 +72,24 @@ def test_ragged_and_edge_reads():
 
 
 def test_read_too_long_reported():
-    s = SynthDb(50, 400, 8, 4)
-    bases, offsets, _ = s.reads(10, 300)
+    s = SynthDb(50, 700, 8, 4)
+    bases, offsets, _ = s.reads(10, 600)
     with engine.PlacementDb(s.flat, device=0) as db:
-        got = db.place_batch(bases, offsets)
-        assert 2 * (300 - 8 + 1) > db.info.max_read_kmers
+        got, st = db.place_batch(bases, offsets, want_stats=True)
+        assert 2 * (600 - 8 + 1) > db.info.max_read_kmers
     assert (got["status"] == _abi.ERR_READ_TOO_LONG).all()
+    assert (st["n_query_kmers"] == 2 * (600 - 8 + 1)).all()
+
+
+@pytest.mark.parametrize("collapse", [0.0, 0.4])
+def test_mixed_read_lengths_use_both_kernels(collapse):
+    """Reads of 0..500 bp: the 320-k-mer and the 1024-k-mer kernels in one batch."""
+    s = SynthDb(120, 600, 9, 4, collapse_prob=collapse)
+    rng = np.random.default_rng(9)
+    bases, offsets = ragged_reads(rng, s, 600, 0, 500)
+    _check(s.flat, bases, offsets, {})
+    _check(s.flat, bases, offsets, dict(remove_intersection=True))
+    _check(drop_random_nodes(s.flat, 0.2, seed=4), bases, offsets, {})
 
 
 def test_empty_batch_and_offsets_base():
