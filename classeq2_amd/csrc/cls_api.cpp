@@ -62,6 +62,7 @@ struct cls_db {
     void* d_table = nullptr;
     void* d_postings = nullptr;
     void* d_bucket_key = nullptr;
+    void* d_direct = nullptr;
     std::mutex ws_mu;
     std::vector<Workspace> ws;  // per-call scratch (class lists, child counters), recycled once their launch has finished
 };
@@ -89,6 +90,7 @@ extern "C" void cls_db_destroy(cls_db* db) {
     if (db->d_table) (void)hipFree(db->d_table);
     if (db->d_postings) (void)hipFree(db->d_postings);
     if (db->d_bucket_key) (void)hipFree(db->d_bucket_key);
+    if (db->d_direct) (void)hipFree(db->d_direct);
     if (have_prev) (void)hipSetDevice(prev);
     delete db;
 }
@@ -122,7 +124,8 @@ extern "C" int cls_db_create(const cls_db_desc* d, int device, cls_db** out) {
         if ((e = up(&db->d_nodes, E.nodes.data(), E.nodes.size() * sizeof(cls::DNode))) != hipSuccess ||
             (e = up(&db->d_table, E.table.data(), E.table.size() * sizeof(cls::Slot))) != hipSuccess ||
             (e = up(&db->d_postings, E.postings.data(), E.postings.size() * 4)) != hipSuccess ||
-            (e = up(&db->d_bucket_key, E.bucket_key.data(), E.bucket_key.size() * 8)) != hipSuccess) {
+            (e = up(&db->d_bucket_key, E.bucket_key.data(), E.bucket_key.size() * 8)) != hipSuccess ||
+            (!E.direct.empty() && (e = up(&db->d_direct, E.direct.data(), E.direct.size() * 4)) != hipSuccess)) {
             cls_db_destroy(db);
             return fail(e == hipErrorOutOfMemory ? CLS_E_NOMEM : CLS_E_HIP, std::string("cls_db_create: upload failed: ") + hipGetErrorString(e));
         }
@@ -131,6 +134,7 @@ extern "C" int cls_db_create(const cls_db_desc* d, int device, cls_db** out) {
         v.table = (const cls::Slot*)db->d_table;
         v.postings = (const uint32_t*)db->d_postings;
         v.bucket_key = (const uint64_t*)db->d_bucket_key;
+        v.direct = (const uint32_t*)db->d_direct;
         v.table_mask = E.table.size() - 1;
         v.n_nodes = (uint32_t)E.nodes.size();
         v.n_buckets = (uint32_t)E.bucket_key.size();
@@ -149,7 +153,7 @@ extern "C" int cls_db_create(const cls_db_desc* d, int device, cls_db** out) {
         i.n_closed_kmers = E.n_closed;
         i.table_slots = E.table.size();
         i.postings_words = E.postings.size();
-        i.hbm_bytes = E.nodes.size() * sizeof(cls::DNode) + E.table.size() * sizeof(cls::Slot) + E.postings.size() * 4 + E.bucket_key.size() * 8;
+        i.hbm_bytes = E.nodes.size() * sizeof(cls::DNode) + E.table.size() * sizeof(cls::Slot) + E.postings.size() * 4 + E.bucket_key.size() * 8 + E.direct.size() * 4;
         i.max_read_kmers = cls::MAX_READ_KMERS;
         i.device = device;
         *out = db;

@@ -3,6 +3,8 @@
 // cls_db_create(); nothing here is on the timed path.
 #include "cls_db.h"
 
+#include "cls_murmur.h"
+
 #include <algorithm>
 #include <atomic>
 #include <functional>
@@ -76,8 +78,8 @@ int encode_db(const cls_db_desc* d, EncodedDb& E, std::string& err) {
         const cls_node& n = d->nodes[order[r]];
         DNode& o = E.nodes[r];
         o.id = n.id;
-        o.n_children = n.n_children;
-        o.flags = n.has_children ? 1u : 0u;
+        o.split = 0;
+        o.flags = (n.has_children ? 1u : 0u) | (std::min<uint32_t>(n.n_children, (1u << 24) - 1) << 8);
         o.n_nonleaf = 0;
         o.first_child = 0;
         if (n.n_children) {
@@ -104,7 +106,7 @@ int encode_db(const cls_db_desc* d, EncodedDb& E, std::string& err) {
         while (!st.empty()) {
             Fr& f = st.back();
             DNode& n = E.nodes[f.row];
-            if (f.next < n.n_children) {
+            if (f.next < d->nodes[order[f.row]].n_children) {
                 uint32_t c = n.first_child + f.next++;
                 E.nodes[c].pre = counter++;
                 row_by_pre[E.nodes[c].pre] = c;
@@ -115,6 +117,7 @@ int encode_db(const cls_db_desc* d, EncodedDb& E, std::string& err) {
             } else {
                 n.size = counter - n.pre;
                 size_by_pre[n.pre] = n.size;
+                if (d->nodes[order[f.row]].n_children) n.split = E.nodes[n.first_child].pre + E.nodes[n.first_child].size;
                 st.pop_back();
             }
         }
@@ -199,17 +202,19 @@ int encode_db(const cls_db_desc* d, EncodedDb& E, std::string& err) {
     const uint64_t* d_kmer_hash = d->kmer_hash;
     E.strictly_binary = true;
     for (uint32_t r = 0; r < N; ++r)
-        if (E.nodes[r].n_children != 0 && E.nodes[r].n_children != 2) { E.strictly_binary = false; break; }
+        if (d->nodes[order[r]].n_children != 0 && d->nodes[order[r]].n_children != 2) { E.strictly_binary = false; break; }
     E.format = (E.strictly_binary && n_closed.load() == NK) ? FMT_SPLIT : FMT_LIST;
     if (E.format == FMT_SPLIT) {
         // per k-mer: 2 header records + (n-1) split nodes + (n == 1 ? 0 : 0) ... see cls_device.h
         std::vector<uint64_t> rec_off(NK + 1, 0);
+        rec_off[0] = SPLIT_FIRST_REC;  // records 0/1: the dummy "no k-mer" header
         for (uint64_t j = 0; j < NK; ++j) {
             const uint32_t n = E.postings[kmer_off[j]] & POST_LEN_MASK;
             rec_off[j + 1] = rec_off[j] + SPLIT_HEADER_RECS + (n ? n - 1 : 0);
         }
         if (rec_off[NK] >= (1ULL << 32)) { err = "split-tree postings exceed 2^32 records"; return CLS_E_BAD_DB; }
         std::vector<uint32_t> recs((rec_off[NK] + 1) * 4, 0);
+        recs[2] = 0xFFFFFFFFu;  // dummy header {0, 0, first tip = MAX, last tip = 0}: decodes to "inactive"
         parallel_chunks(NK, nt, [&](unsigned, uint64_t lo, uint64_t hi) {
             std::vector<uint32_t> d, stk, L, R, pos, span_lo, span_hi;
             for (uint64_t j = lo; j < hi; ++j) {
@@ -264,10 +269,10 @@ int encode_db(const cls_db_desc* d, EncodedDb& E, std::string& err) {
                 h[7] = bucket_of[j];
                 for (uint32_t i = 1; i < n; ++i) {
                     uint32_t* t = &recs[(size_t)at(i) * 4];
-                    t[0] = tip[i];
-                    t[1] = tip[i - 1];
-                    t[2] = L[i] ? at(L[i]) : 0;
-                    t[3] = R[i] ? at(R[i]) : 0;
+                    t[0] = tip[i - 1];              // descending into the LEFT part: new last tip ...
+                    t[1] = L[i] ? at(L[i]) : 0;     // ... and its split
+                    t[2] = tip[i];                  // descending into the RIGHT part: new first tip ...
+                    t[3] = R[i] ? at(R[i]) : 0;     // ... and its split
                 }
             }
         });
@@ -294,6 +299,35 @@ int encode_db(const cls_db_desc* d, EncodedDb& E, std::string& err) {
             i = (i + 1) & mask;
         }
         E.table[i] = Slot{h, (off << LOC_BUCKET_BITS) | bucket_of[j]};
+    }
+    // ---- 6. direct table for small k -----------------------------------------------------
+    if (E.format == FMT_SPLIT && d->k_size <= DIRECT_MAX_K) {
+        const uint32_t K = (uint32_t)d->k_size, M = (uint32_t)std::min<uint64_t>(d->m_size, d->k_size);
+        const uint64_t n_codes = 1ULL << (2 * K);
+        E.direct.assign(n_codes, 0);
+        std::atomic<bool> foreign{false};
+        std::atomic<uint64_t> found{0};
+        parallel_chunks(n_codes, nt, [&](unsigned, uint64_t lo, uint64_t hi) {
+            static const char LETTER[4] = {'A', 'C', 'T', 'G'};  // code = (ascii >> 1) & 3
+            char buf[DIRECT_MAX_K + 1];
+            uint64_t cnt = 0;
+            for (uint64_t code = lo; code < hi; ++code) {
+                for (uint32_t i = 0; i < K; ++i) buf[i] = LETTER[(code >> (2 * i)) & 3];
+                const uint64_t h = murmur3_h1_bytes(buf, K);
+                for (uint64_t i = h & mask; E.table[i].loc != SLOT_EMPTY; i = (i + 1) & mask) {
+                    if (E.table[i].hash != h) continue;
+                    const uint64_t bkey = d->bucket_key[E.table[i].loc & LOC_BUCKET_MASK];
+                    if (bkey != (M ? murmur3_h1_bytes(buf, M) : 0ull)) foreign = true;
+                    E.direct[code] = (uint32_t)(E.table[i].loc >> LOC_BUCKET_BITS);
+                    ++cnt;
+                    break;
+                }
+            }
+            found += cnt;
+        });
+        // an entry filed under a bucket that is not its own prefix's, or a hash no enumerated k-mer
+        // produces (k-mers with non-ACGT letters cannot be queried anyway): keep the generic probe path
+        if (foreign.load() || found.load() != NK) std::vector<uint32_t>().swap(E.direct);
     }
     E.bucket_key.assign(d->bucket_key, d->bucket_key + d->n_buckets);
     if (E.bucket_key.empty()) E.bucket_key.push_back(0);

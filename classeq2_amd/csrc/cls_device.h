@@ -19,8 +19,8 @@ struct DNode {
     uint32_t first_child;   // row of the first (non-LEAF first) child
     uint32_t n_nonleaf;     // children whose kind != LEAF (clade.rs:166-172)
     uint64_t id;            // Clade.id
-    uint32_t n_children;
-    uint32_t flags;         // bit0: has_children (children: Some(..))
+    uint32_t split;         // pre + size of the FIRST child row = where the second child starts (0 if childless)
+    uint32_t flags;         // bit0: has_children (children: Some(..)); bits 8..31: min(n_children, 2^24-1)
 };
 static_assert(sizeof(DNode) == 32, "DNode");
 
@@ -57,7 +57,7 @@ constexpr uint32_t POST_HEADER_WORDS = 2;
 // records + (n-1) split nodes:
 //   header 0 : {n | POST_HAS_ROOT | POST_CLOSED, root split (record index, 0 = none), first tip, last tip}
 //   header 1 : {n_leaf_ids (statistics), hash lo, hash hi, minimizer-bucket index}
-//   split i  : {tip[i], tip[i-1], L, R}            (1 <= i < n)
+//   split i  : {tip[i-1], L, tip[i], R}            (1 <= i < n): one 8-byte half per direction
 // tip[] = ascending pre-order indices.  Split i is the node of the Cartesian tree
 // over depth(LCA(tip[i-1], tip[i])): for the tips inside one clade's interval the
 // shallowest such LCA is where the clade's two children part them, so L / R
@@ -65,12 +65,24 @@ constexpr uint32_t POST_HEADER_WORDS = 2;
 // Descending one level costs ONE 16-byte read per k-mer that has tips on both
 // sides, and none otherwise.  Split nodes are stored in DFS pre-order, heavier
 // child first, so the successive reads of one k-mer tend to share a 64-byte line.
+// Record 0/1 of the array are a dummy header pair {0, 0, 0xFFFFFFFF, 0}: "no k-mer"
+// reads land there and decode to an inactive state without a branch.
 constexpr uint32_t SPLIT_HEADER_RECS = 2;
+constexpr uint32_t SPLIT_FIRST_REC = 2;
+
+// ---- direct k-mer table (k <= DIRECT_MAX_K, FMT_SPLIT only) ----------------------
+// For small k every possible k-mer is enumerated once at cls_db_create(): its 2-bit
+// code (A=0 C=1 T=2 G=3 = (ascii >> 1) & 3, first base in the low bits) indexes a
+// u32 table holding the record offset of its header (0 = not in the index), so the
+// query side needs neither MurmurHash nor a probe loop.  Only built when every
+// index entry sits in the minimizer bucket of its own prefix (true for every
+// `cls build-db` output), which makes the bucket filter of kmers_map.rs:295-297 a no-op.
+constexpr uint32_t DIRECT_MAX_K = 15;
 struct TipRec {
-    uint32_t tip;
-    uint32_t tip_prev;
-    uint32_t l;
-    uint32_t r;
+    uint32_t tip_prev;  // last tip of the left part
+    uint32_t l;         // split of the left part
+    uint32_t tip;       // first tip of the right part
+    uint32_t r;         // split of the right part
 };
 static_assert(sizeof(TipRec) == 16, "TipRec");
 
@@ -81,6 +93,7 @@ struct DbDev {
     const Slot* table;
     const uint32_t* postings;   // FMT_LIST: u32 words; FMT_SPLIT: TipRec records (16-byte units)
     const uint64_t* bucket_key;
+    const uint32_t* direct;     // 4^k entries or nullptr
     uint64_t table_mask;
     uint32_t n_nodes;
     uint32_t n_buckets;

@@ -617,8 +617,8 @@ __device__ __forceinline__ void place_read_split(const DbDev db, const PlacePara
             for (int i = 0; i < G; ++i) {
                 const int s = g0 + i;
                 if (s >= SLOTS || !((need >> i) & 1u)) continue;
-                if (best == 0) { vhi[s] = t[i].y; x[s] = t[i].z; }
-                else { vlo[s] = t[i].x; x[s] = t[i].w; }
+                if (best == 0) { vhi[s] = t[i].x; x[s] = t[i].y; }
+                else { vlo[s] = t[i].z; x[s] = t[i].w; }
             }
         }
         if (best != 0) {
@@ -683,6 +683,260 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, MIN_WAVES_PER_EU) void place_
     }
 }
 
+// ---- fast path: FMT_SPLIT + direct 2-bit k-mer table ---------------------------------------------
+// Same algorithm as place_read_split, written for instruction economy (the split kernel was bound by
+// instruction issue, the scalar unit above all): no MurmurHash (the 2-bit code of a k-mer indexes the
+// direct table), no probe loop, no per-slot branches (an absent / inactive k-mer is the state
+// {vlo = MAX, vhi = 0}), one DPP reduction per level instead of 3*SLOTS ballots, and the two children's
+// node records fetched ahead of the counting.
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xb1, 0xf, 0xf, true);   // quad_perm:[1,0,3,2]
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4e, 0xf, 0xf, true);   // quad_perm:[2,3,0,1]
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true);  // row_shr:4
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true);  // row_shr:8
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, true);  // row_bcast:15 -> rows 1,3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, true);  // row_bcast:31 -> rows 2,3
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+
+// A DNode read through the constant address space: wave-uniform address -> s_load_dwordx8
+// (scalar cache, no vector-memory instruction).  {pre, size, first_child, n_nonleaf, id lo, id hi, split, flags}
+struct snode_t { uint32_t s[8]; };
+__device__ __forceinline__ snode_t load_node(const DNode* nodes, uint32_t row) {
+    typedef __attribute__((address_space(4))) const uint32_t as4_u32;
+    as4_u32* p = (as4_u32*)(uintptr_t)(nodes + __builtin_amdgcn_readfirstlane(row));
+    snode_t r;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r.s[i] = p[i];
+    return r;
+}
+
+struct FastCtx {
+    uint8_t* ascii;    // LDS: upper-cased read, L bytes
+    uint32_t* packed;  // LDS: the read 2 bits per base, base i at bits 2(i & 15) of word i >> 4
+    uint32_t* set;     // LDS: distinct-hit set keyed by header record offset
+};
+
+template <int SLOTS, int SET_BITS, bool STATS>
+__device__ __forceinline__ void place_read_fast(const DbDev& db, const PlaceParams& prm, const FastCtx& cx,
+                                                const uint8_t* __restrict__ bases, uint64_t b0, uint64_t b1, uint32_t r,
+                                                cls_placement* __restrict__ out, cls_query_stats* __restrict__ stats,
+                                                uint32_t profile_stop) {
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t k = db.k;
+    const uint64_t L64 = b1 - b0;
+    auto put_stats = [&](uint32_t nk_, uint32_t nm, uint32_t nr, uint64_t lp) {
+        if (STATS && stats && lane == 0) {
+            uint64_t* s = reinterpret_cast<uint64_t*>(stats + r);
+            s[0] = (uint64_t)nk_ | ((uint64_t)nm << 32);
+            s[1] = (uint64_t)nr;
+            s[2] = lp;
+        }
+    };
+    if (L64 < k) { put_stats(0, 0, 0, 0); write_record(out, r, CLS_ERR_TOO_FEW_KMERS, 0, 0, 0, 0); return; }
+    const uint32_t L = (uint32_t)L64, nf = L - k + 1, nk = 2 * nf;  // nk <= 64*SLOTS by classification
+    // ---- A1. load + validate + 2-bit pack --------------------------------------------------------
+    bool bad = false;
+#pragma unroll 1
+    for (uint32_t i = lane; i < L; i += 64) {
+        uint8_t c = bases[b0 + i];
+        if (c >= 'a' && c <= 'z') c -= 32;
+        bad |= !(c == 'A' || c == 'C' || c == 'G' || c == 'T');
+        cx.ascii[i] = c;
+    }
+#pragma unroll 1
+    for (uint32_t i = lane; i < (1u << SET_BITS); i += 64) cx.set[i] = SET_EMPTY;
+    if (__ballot(bad)) { put_stats(0, 0, 0, 0); write_record(out, r, CLS_ERR_INVALID_BASE, 0, 0, 0, 0); return; }
+    wave_sync();
+    {
+        const uint32_t n_words = (L + 15) >> 4;
+#pragma unroll 1
+        for (uint32_t w = lane; w < n_words; w += 64) {
+            uint32_t acc = 0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {  // 4 ascii bytes -> 8 bits: (c >> 1) & 3 = A0 C1 T2 G3
+                uint32_t t = *reinterpret_cast<const uint32_t*>(cx.ascii + 16 * w + 4 * q);  // reads past L stay inside the buffer
+                t = (t >> 1) & 0x03030303u;
+                t = (t | (t >> 6) | (t >> 12) | (t >> 18)) & 0xFFu;
+                acc |= t << (8 * q);
+            }
+            cx.packed[w] = acc;
+        }
+    }
+    wave_sync();
+    // ---- A2. per k-mer: code -> direct table -> distinct set -> header ------------------------------
+    const uint32_t* __restrict__ direct = db.direct;
+    const uint4* __restrict__ recs = reinterpret_cast<const uint4*>(db.postings);
+    const uint32_t kmask = (k == 16) ? 0xFFFFFFFFu : ((1u << (2 * k)) - 1u);
+    uint32_t off[SLOTS];
+#pragma unroll
+    for (int s = 0; s < SLOTS; ++s) {
+        const uint32_t j = s * 64 + lane;
+        const bool valid = j < nk;
+        const bool rc = j >= nf;
+        const uint32_t p = valid ? (rc ? (nf - 1) - (j - nf) : j) : 0;  // window start; the rc list runs backwards over the windows
+        const uint32_t w = p >> 4, sh = (2 * p) & 31;
+        const uint32_t d0 = cx.packed[w], d1 = cx.packed[w + 1];
+        uint32_t code = (uint32_t)((((uint64_t)d1 << 32) | d0) >> sh) & kmask;
+        // reverse complement of the window: complement = code ^ 0b10.., then reverse the 2-bit groups
+        uint32_t rcc = __builtin_bitreverse32(code ^ (0xAAAAAAAAu & kmask));
+        rcc = ((rcc >> 1) & 0x55555555u) | ((rcc & 0x55555555u) << 1);
+        rcc >>= (32 - 2 * k);
+        code = rc ? rcc : code;
+        off[s] = valid ? direct[code] : 0u;
+    }
+    // distinct hashes: the FIRST k-mer that reaches an entry keeps it (HashSet<u64> semantics)
+#pragma unroll
+    for (int s = 0; s < SLOTS; ++s) {
+        if (off[s] != 0) {
+            const uint32_t key = off[s];
+            uint32_t pos = (key * 2654435761u) >> (32 - SET_BITS);
+#pragma unroll 1
+            for (;;) {
+                const uint32_t old = atomicCAS(&cx.set[pos], SET_EMPTY, key);
+                if (old == SET_EMPTY) break;
+                if (old == key) { off[s] = 0; break; }
+                pos = (pos + 1) & ((1u << SET_BITS) - 1);
+            }
+        }
+    }
+    if (profile_stop == 1) { write_record(out, r, 0xFE, (int32_t)(off[0] + off[SLOTS - 1]), 0, 0, 0); return; }  // profiling aid
+    // ---- A3. state from the headers (record 0 = the dummy "inactive" header) --------------------------
+    uint32_t vlo[SLOTS], vhi[SLOTS], x[SLOTS];
+    uint32_t cnt = 0;  // |M| in bits 0..15, |M_root| in bits 16..31 (per lane, then summed)
+    uint64_t leafp = 0;
+#pragma unroll
+    for (int s = 0; s < SLOTS; ++s) {
+        const uint4 hd = recs[off[s]];  // {n | flags, root split, first tip, last tip}
+        if (STATS) leafp += recs[off[s] + 1].x;
+        vlo[s] = hd.z;
+        vhi[s] = hd.w;
+        x[s] = hd.y;
+        cnt += (off[s] != 0 ? 1u : 0u) + ((hd.x >> 31) << 16);
+    }
+    cnt = wave_sum(cnt);
+    const uint32_t n_m = cnt & 0xFFFFu, n_root = cnt >> 16;
+    if (STATS) {
+        for (int o = 32; o > 0; o >>= 1) leafp += ((uint64_t)__shfl_xor((uint32_t)(leafp >> 32), o) << 32) | __shfl_xor((uint32_t)leafp, o);
+        put_stats(nk, n_m, n_root, leafp);
+    }
+    if (profile_stop == 2) { write_record(out, r, 0xFE, (int32_t)(vlo[0] + vhi[SLOTS - 1] + x[1]), 0, 0, 0); return; }
+    // ---- B. thresholds ------------------------------------------------------------------------------
+    if (n_m == 0) { write_record(out, r, CLS_UNCLASSIFIABLE_NO_MATCH, 0, 0, 0, 0); return; }
+    if (n_root == 0) { write_record(out, r, CLS_UNCLASSIFIABLE_NO_ROOT, 0, 0, 0, 0); return; }
+    // node records through the scalar unit: a DNode is 8 dwords {pre, size, first_child, n_nonleaf, id lo, id hi, split, flags}
+    snode_t P = load_node(db.nodes, 0);
+    if (!(P.s[7] & 1u)) { write_record(out, r, CLS_ERR_ROOT_NO_CHILDREN, 0, 0, 0, 0); return; }
+    {
+        const double expected = round((double)n_m * prm.min_match_coverage);
+        const uint64_t exp_usize = (expected != expected) ? 0ull : (uint64_t)expected;
+        if ((uint64_t)n_root < exp_usize) { write_record(out, r, CLS_UNCLASSIFIABLE_COVERAGE, (int32_t)n_root, 0, 0, 0); return; }
+    }
+    // ---- C. descent -----------------------------------------------------------------------------------
+    const uint2* __restrict__ half = reinterpret_cast<const uint2*>(db.postings);  // record x = halves 2x (left), 2x+1 (right)
+    const bool rm = prm.remove_intersection != 0;
+    int32_t iteration = 0;
+    for (;;) {
+        ++iteration;
+        if (iteration > prm.max_iterations) { write_record(out, r, CLS_ERR_MAX_ITER, 0, 0, (uint32_t)iteration, 0); return; }
+        const uint32_t fc = P.s[2], m = P.s[3];
+        const uint32_t a0 = P.s[0] + 1, a1 = P.s[6];  // first child = [a0, a1), second = [a1, end of the parent)
+        // both children's records, requested ahead of the counting
+        const snode_t CA = load_node(db.nodes, fc), CB = load_node(db.nodes, fc + 1);
+        uint32_t c3 = 0, c3b = 0;  // per lane: |in a| | |in b| << 10 | |in both| << 20
+#pragma unroll
+        for (int s = 0; s < SLOTS; ++s) {
+            const uint32_t ina = vlo[s] < a1 ? 1u : 0u;   // vlo >= a0 for an active k-mer, MAX for an inactive one
+            const uint32_t inb = vhi[s] >= a1 ? 1u : 0u;  // vhi < end of the parent for an active one, 0 for an inactive one
+            if (SLOTS * 64 < 1024) c3 += ina | (inb << 10) | ((ina & inb) << 20);
+            else { c3 += ina | (inb << 16); c3b += ina & inb; }
+        }
+        uint32_t cnt_a, cnt_b, both;
+        if (SLOTS * 64 < 1024) {
+            c3 = wave_sum(c3);
+            cnt_a = c3 & 0x3FFu; cnt_b = (c3 >> 10) & 0x3FFu; both = c3 >> 20;
+        } else {
+            c3 = wave_sum(c3); c3b = wave_sum(c3b);
+            cnt_a = c3 & 0xFFFFu; cnt_b = c3 >> 16; both = c3b;
+        }
+        if (m == 0) cnt_a = 0;                 // no non-LEAF child: nothing is scored (:322-324)
+        if (m < 2) { cnt_b = 0; both = 0; }   // the second child is a LEAF
+        // (one, rest) of place_sequence.rs:369-395 with |R_c| = |U| - |only_c|, |R_c \ K_c| = |U| - |K_c|:
+        //   one_a - rest_a = |only_a| - |only_b| = -(one_b - rest_b)   for either remove_intersection,
+        // so exactly one child passes `one > rest` when the two differ and none when they tie.
+        const uint32_t only_a = cnt_a - both, only_b = cnt_b - both, U = cnt_a + cnt_b - both;
+        const uint64_t pid = ((uint64_t)P.s[5] << 32) | P.s[4];
+        if (only_a == only_b) {
+            if (iteration == 1) write_record(out, r, CLS_UNCLASSIFIABLE_LEVEL1, 0, 0, 1, 0);
+            else write_record(out, r, CLS_MAX_RESOLUTION, 0, 0, (uint32_t)iteration, pid);
+            return;
+        }
+        const bool right = only_b > only_a;
+        P = right ? CB : CA;
+        if (P.s[3] == 0) {  // no non-LEAF child below the chosen clade (update_introspection_node.rs:45-85)
+            const uint32_t cn = right ? cnt_b : cnt_a, on = right ? only_b : only_a;
+            write_record(out, r, CLS_IDENTITY_FOUND, (int32_t)(rm ? on : cn), (int32_t)(rm ? U - cn : U - on), (uint32_t)iteration,
+                         ((uint64_t)P.s[5] << 32) | P.s[4]);
+            return;
+        }
+        // narrow: a k-mer with tips on both sides of a1 reads 8 bytes of its split node; everything else
+        // is arithmetic on (vlo, vhi).  Inactive afterwards = {MAX, 0}.
+        if (!right) {
+            uint2 t[SLOTS];
+#pragma unroll
+            for (int s = 0; s < SLOTS; ++s) {
+                const bool str = vlo[s] < a1 && vlo[s] != a0 && vhi[s] >= a1;
+                t[s] = profile_stop == 3 ? uint2{vhi[s] >> 1, x[s]} : half[str ? 2 * (size_t)x[s] : 0];
+            }
+#pragma unroll
+            for (int s = 0; s < SLOTS; ++s) {
+                const bool gone = vlo[s] >= a1 || vlo[s] == a0;  // no tip strictly below the first child
+                const bool str = !gone && vhi[s] >= a1;
+                if (str) { vhi[s] = t[s].x; x[s] = t[s].y; }
+                if (gone) { vlo[s] = 0xFFFFFFFFu; vhi[s] = 0; }
+            }
+        } else {
+            uint2 t[SLOTS];
+#pragma unroll
+            for (int s = 0; s < SLOTS; ++s) {
+                const bool str = vhi[s] >= a1 && vlo[s] < a1;
+                t[s] = profile_stop == 3 ? uint2{vlo[s] + 1, x[s]} : half[str ? 2 * (size_t)x[s] + 1 : 0];
+            }
+#pragma unroll
+            for (int s = 0; s < SLOTS; ++s) {
+                const bool str = vhi[s] >= a1 && vlo[s] < a1;
+                if (str) { vlo[s] = t[s].x; x[s] = t[s].y; }
+                const bool gone = vhi[s] < a1 || vlo[s] == a1;  // nothing in the second child, or it is the tip itself
+                if (gone) { vlo[s] = 0xFFFFFFFFu; vhi[s] = 0; }
+            }
+        }
+    }
+}
+
+template <int SLOTS, int SET_BITS, bool STATS>
+__global__ __launch_bounds__(64 * WAVES_PER_BLOCK, MIN_WAVES_PER_EU) void place_fast_kernel(
+    DbDev db, PlaceParams prm, const uint8_t* __restrict__ bases, const uint64_t* __restrict__ offsets,
+    const uint32_t* __restrict__ list, const uint32_t* __restrict__ list_len, cls_placement* __restrict__ out,
+    cls_query_stats* __restrict__ stats, uint32_t ascii_cap, uint32_t profile_stop) {
+    extern __shared__ __align__(16) uint8_t smem[];
+    const uint32_t wave = threadIdx.x >> 6;
+    const uint32_t packed_words = (ascii_cap >> 4) + 2;
+    const uint32_t per_wave = ascii_cap + 4u * packed_words + (4u << SET_BITS);
+    FastCtx cx;
+    cx.ascii = smem + wave * per_wave;
+    cx.packed = reinterpret_cast<uint32_t*>(cx.ascii + ascii_cap);
+    cx.set = cx.packed + packed_words;
+    const uint32_t gw = blockIdx.x * WAVES_PER_BLOCK + wave;
+    const uint32_t n_waves = gridDim.x * WAVES_PER_BLOCK;
+    const uint32_t n_list = *list_len;
+    for (uint32_t i = gw; i < n_list; i += n_waves) {
+        const uint32_t r = list[i];
+        const uint64_t b0 = offsets[r], b1 = offsets[r + 1];
+        place_read_fast<SLOTS, SET_BITS, STATS>(db, prm, cx, bases, b0, b1, r, out, stats, profile_stop);
+        wave_sync();
+    }
+}
+
 // ---- read-length classes ----------------------------------------------------------------------
 // One thread per read: reads are binned by their k-mer count into the kernel wide enough for
 // them (class lists in device memory; nothing returns to the host).  Reads no kernel can hold
@@ -726,13 +980,25 @@ constexpr int N_CLASSES = 2;
 constexpr int CLS_SLOTS[N_CLASSES] = {5, 16};      // k-mers per read: 320 / 1024
 constexpr int CLS_SET_BITS[N_CLASSES] = {9, 11};   // LDS distinct-hit set: 512 / 2048 entries
 
+bool use_fast(const DbDev& db) {
+    static const bool off = getenv("CLS_NO_FAST") != nullptr;  // A/B experiments
+    return db.format == FMT_SPLIT && db.direct != nullptr && !off;
+}
 uint32_t seq_cap_of(const DbDev& db, int c) { return (2 * (64 * CLS_SLOTS[c] / 2 + db.k) + 15) & ~15u; }
+// fast path: L <= 32*SLOTS + k - 1 ascii bytes (+ padding so that the 16-byte packer can over-read)
+uint32_t ascii_cap_of(const DbDev& db, int c) { return (64 * CLS_SLOTS[c] / 2 + db.k + 16 + 15) & ~15u; }
 size_t smem_of(const DbDev& db, int c) {
+    if (use_fast(db)) {
+        const uint32_t ac = ascii_cap_of(db, c);
+        return (size_t)WAVES_PER_BLOCK * (ac + 4u * ((ac >> 4) + 2) + (4u << CLS_SET_BITS[c]));
+    }
     return (size_t)WAVES_PER_BLOCK * (seq_cap_of(db, c) + (4u << CLS_SET_BITS[c]) + 4u * 64 * CLS_SLOTS[c]);
 }
 
 template <int SLOTS, int SET_BITS>
 const void* kernel_of_t(const DbDev& db, bool stats) {
+    if (use_fast(db))
+        return stats ? (const void*)place_fast_kernel<SLOTS, SET_BITS, true> : (const void*)place_fast_kernel<SLOTS, SET_BITS, false>;
     if (db.format == FMT_SPLIT)
         return stats ? (const void*)place_split_kernel<SLOTS, SET_BITS, true> : (const void*)place_split_kernel<SLOTS, SET_BITS, false>;
     const bool binary = db.max_nonleaf_arity <= 2;  // no node has more than two non-LEAF children
@@ -797,6 +1063,14 @@ hipError_t launch_place(const DbDev& db, const PlaceParams& prm, const PlacePlan
         const dim3 grid(plan.grid[c]), block(64 * WAVES_PER_BLOCK);
         const uint32_t seq_cap = seq_cap_of(db, c);
         const size_t smem = smem_of(db, c);
+        if (use_fast(db)) {
+            const uint32_t ac = ascii_cap_of(db, c);
+            if (st) hipLaunchKernelGGL((place_fast_kernel<SLOTS, SET_BITS, true>), grid, block, smem, stream, db, prm, d_bases, d_offsets,
+                                       lists[c], counts + c, d_out, d_stats, ac, profile_stop);
+            else hipLaunchKernelGGL((place_fast_kernel<SLOTS, SET_BITS, false>), grid, block, smem, stream, db, prm, d_bases, d_offsets,
+                                    lists[c], counts + c, d_out, d_stats, ac, profile_stop);
+            return;
+        }
         if (db.format == FMT_SPLIT) {
             if (st) hipLaunchKernelGGL((place_split_kernel<SLOTS, SET_BITS, true>), grid, block, smem, stream, db, prm, d_bases, d_offsets,
                                        lists[c], counts + c, d_out, d_stats, seq_cap, profile_stop);

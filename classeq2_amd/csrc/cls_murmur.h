@@ -6,6 +6,7 @@
 #include <stdint.h>
 
 #if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
 #define CLS_HD __host__ __device__ __forceinline__
 #else
 #define CLS_HD inline

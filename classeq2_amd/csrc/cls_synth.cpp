@@ -323,6 +323,10 @@ extern "C" uint32_t cls_synth_max_depth(const cls_synth_db* s) { return s->max_d
 extern "C" uint64_t cls_synth_leaf_id(const cls_synth_db* s, uint32_t i) { return s->nodes[s->leaf_row[i]].id; }
 extern "C" const char* cls_synth_leaf_seq(const cls_synth_db* s, uint32_t i) { return &s->leaf_seq[(size_t)i * s->cfg.ref_len]; }
 
+// experiment hook: when set, cls_synth_reads also records each read's start coordinate here
+static uint32_t* g_truth_pos = nullptr;
+extern "C" void cls_synth_set_truth_pos(uint32_t* p) { g_truth_pos = p; }
+
 extern "C" int cls_synth_reads(const cls_synth_db* s, uint64_t seed, uint64_t first, uint32_t n_reads,
                                uint32_t read_len, double err, double frac_random, char* bases,
                                uint64_t* offsets, uint32_t* truth_leaf) {
@@ -347,6 +351,7 @@ extern "C" int cls_synth_reads(const cls_synth_db* s, uint64_t seed, uint64_t fi
             else memcpy(o, src, read_len);
             for (uint32_t j = 0; j < read_len; ++j) if (rng.unit() < err) o[j] = other_base(o[j], rng);
             if (truth_leaf) truth_leaf[i] = li;
+            if (g_truth_pos) g_truth_pos[i] = st;
         }
     }
     for (uint64_t i = 0; i <= n_reads; ++i) offsets[i] = i * (uint64_t)read_len;
