@@ -35,6 +35,21 @@ def algorithmic_bytes(read_lens, stats):
         stats["leaf_postings"].astype(np.int64).sum()) + 24 * len(stats)
 
 
+def traffic_lookup(config, reads):
+    """HBM bytes per launch of the dominant kernel from the rocprofv3 PMC passes committed under
+    profiles/ (FETCH_SIZE / WRITE_SIZE collected in separate --pmc runs of this same command and
+    corrected as /opt/skills/guides/MI355X_MICROARCH.md prescribes); null if this workload was not profiled."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+            return json.load(f).get(f"{config}:{reads}", {}).get("hbm_bytes_per_launch")
+    except (OSError, ValueError):
+        return None
+
+
+def db_kernel_name(db):
+    return "place_fast_kernel<5,9>" if db.info.k_size <= 15 else "place_split_kernel<5,9>"
+
+
 def cpu_baseline(synth, cfg, budget_s=15.0):
     """The C oracle (oracle/cls_oracle.c, kind "port") on this host's cores, on
     a bounded prefix of the same read stream."""
@@ -132,6 +147,7 @@ def main():
             dist.gather(d_out, gathered, dst=0)
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     sync_all()
+    db.kernel_time(reset=True)  # HIP-event accumulators around the dominant kernel (cls_db_kernel_time)
     t0 = time.perf_counter()
     for i in range(args.steps):
         ev[i][0].record()
@@ -141,7 +157,9 @@ def main():
             dist.gather(d_out, gathered, dst=0)  # the path's one collective: placement records -> rank 0
     sync_all()
     elapsed = time.perf_counter() - t0
-    kernel_ms = sum(a.elapsed_time(b) for a, b in ev) / args.steps
+    call_ms = sum(a.elapsed_time(b) for a, b in ev) / args.steps          # whole C-ABI call (all its kernels)
+    k_sum, k_cnt = db.kernel_time(reset=True)                             # the placement kernel alone, same launches
+    kernel_ms = k_sum / max(1, k_cnt)
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -183,8 +201,9 @@ def main():
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                "kernel": "place_wave_kernel", "kernel_ms": kernel_ms,
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic_lookup(args.config, per_gpu),
+                "kernel": db_kernel_name(db), "kernel_ms": kernel_ms, "kernel_launches_timed": int(k_cnt),
+                "call_ms": call_ms,
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "algorithmic_bytes_per_read": alg_bytes / per_gpu,
             },

@@ -34,6 +34,8 @@ struct Workspace {
     uint32_t* ptr = nullptr;
     uint64_t words = 0;
     hipEvent_t done = nullptr;
+    hipEvent_t t0 = nullptr, t1 = nullptr;  // around the dominant kernel of the launch that used this slot
+    bool timed = false;                     // t0/t1 hold an un-harvested measurement
     bool busy = false;
 };
 
@@ -64,6 +66,8 @@ struct cls_db {
     void* d_bucket_key = nullptr;
     void* d_direct = nullptr;
     std::mutex ws_mu;
+    double kernel_ms_sum = 0.0;
+    uint64_t kernel_launches = 0;
     std::vector<Workspace> ws;  // per-call scratch (class lists, child counters), recycled once their launch has finished
 };
 
@@ -84,6 +88,8 @@ extern "C" void cls_db_destroy(cls_db* db) {
     (void)hipSetDevice(db->device);
     for (auto& w : db->ws) {
         if (w.done) { (void)hipEventSynchronize(w.done); (void)hipEventDestroy(w.done); }
+        if (w.t0) (void)hipEventDestroy(w.t0);
+        if (w.t1) (void)hipEventDestroy(w.t1);
         if (w.ptr) (void)hipFree(w.ptr);
     }
     if (db->d_nodes) (void)hipFree(db->d_nodes);
@@ -188,17 +194,29 @@ extern "C" int cls_db_info_get(const cls_db* db, cls_db_info* info) {
     return CLS_OK;
 }
 
+// fold a finished slot's kernel timing into the handle's accumulators (ws_mu held)
+static void harvest(cls_db* db, Workspace& w) {
+    if (!w.timed) return;
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, w.t0, w.t1) == hipSuccess) { db->kernel_ms_sum += ms; db->kernel_launches++; }
+    w.timed = false;
+}
+
 // Take (or add) a scratch workspace whose previous user has finished.
 static int acquire_ws(cls_db* db, uint64_t words, size_t* slot) {
     std::lock_guard<std::mutex> g(db->ws_mu);
     for (size_t i = 0; i < db->ws.size(); ++i) {
         Workspace& w = db->ws[i];
-        if (w.busy && hipEventQuery(w.done) == hipSuccess) w.busy = false;
+        if (w.busy && hipEventQuery(w.done) == hipSuccess) { w.busy = false; harvest(db, w); }
         if (!w.busy && w.words >= words) { w.busy = true; *slot = i; return CLS_OK; }
     }
     Workspace w;
     if (hipMalloc((void**)&w.ptr, words * 4) != hipSuccess) return fail(CLS_E_NOMEM, "scratch workspace allocation failed");
-    if (hipEventCreateWithFlags(&w.done, hipEventDisableTiming) != hipSuccess) { (void)hipFree(w.ptr); return fail(CLS_E_HIP, "hipEventCreate failed"); }
+    if (hipEventCreateWithFlags(&w.done, hipEventDisableTiming) != hipSuccess || hipEventCreate(&w.t0) != hipSuccess ||
+        hipEventCreate(&w.t1) != hipSuccess) {
+        (void)hipFree(w.ptr);
+        return fail(CLS_E_HIP, "hipEventCreate failed");
+    }
     w.words = words;
     w.busy = true;
     db->ws.push_back(w);
@@ -219,16 +237,31 @@ extern "C" int cls_place_batch_device(cls_db* db, const void* d_bases, const voi
         int rc = acquire_ws(db, (plan.ws_bytes + 3) / 4, &slot);
         if (rc != CLS_OK) return rc;
         hipError_t e = cls::launch_place(db->dev, prm, plan, (const uint8_t*)d_bases, (const uint64_t*)d_offsets, n,
-                                         (cls_placement*)d_out, (cls_query_stats*)d_stats, db->ws[slot].ptr, stream);
+                                         (cls_placement*)d_out, (cls_query_stats*)d_stats, db->ws[slot].ptr, stream,
+                                         db->ws[slot].t0, db->ws[slot].t1);
         {
             std::lock_guard<std::mutex> g(db->ws_mu);
-            if (hipEventRecord(db->ws[slot].done, stream) != hipSuccess) db->ws[slot].busy = false;
+            db->ws[slot].timed = (e == hipSuccess);
+            if (hipEventRecord(db->ws[slot].done, stream) != hipSuccess) { db->ws[slot].busy = false; db->ws[slot].timed = false; }
         }
         if (e != hipSuccess) return fail(CLS_E_HIP, std::string("kernel launch failed: ") + hipGetErrorString(e));
         return CLS_OK;
     } catch (...) {
         return fail(CLS_E_INTERNAL, "cls_place_batch_device: unknown exception");
     }
+}
+
+extern "C" int cls_db_kernel_time(cls_db* db, double* sum_ms, uint64_t* launches, int reset) {
+    if (!db) return fail(CLS_E_INVALID_ARG, "cls_db_kernel_time: null handle");
+    std::lock_guard<std::mutex> g(db->ws_mu);
+    for (auto& w : db->ws) {
+        if (w.busy) { if (hipEventSynchronize(w.done) != hipSuccess) return fail(CLS_E_HIP, "hipEventSynchronize failed"); w.busy = false; }
+        harvest(db, w);
+    }
+    if (sum_ms) *sum_ms = db->kernel_ms_sum;
+    if (launches) *launches = db->kernel_launches;
+    if (reset) { db->kernel_ms_sum = 0.0; db->kernel_launches = 0; }
+    return CLS_OK;
 }
 
 static int place_host(cls_db* db, const char* bases, const uint64_t* offsets, uint32_t n, const cls_params* params,

@@ -304,7 +304,8 @@ int encode_db(const cls_db_desc* d, EncodedDb& E, std::string& err) {
     if (E.format == FMT_SPLIT && d->k_size <= DIRECT_MAX_K) {
         const uint32_t K = (uint32_t)d->k_size, M = (uint32_t)std::min<uint64_t>(d->m_size, d->k_size);
         const uint64_t n_codes = 1ULL << (2 * K);
-        E.direct.assign(n_codes, 0);
+        E.direct.assign(2 * n_codes, 0);  // {record offset, locality meta} per code
+        for (uint64_t c = 0; c < n_codes; ++c) E.direct[2 * c + 1] = 0xFFFFFFFFu;
         std::atomic<bool> foreign{false};
         std::atomic<uint64_t> found{0};
         parallel_chunks(n_codes, nt, [&](unsigned, uint64_t lo, uint64_t hi) {
@@ -318,7 +319,12 @@ int encode_db(const cls_db_desc* d, EncodedDb& E, std::string& err) {
                     if (E.table[i].hash != h) continue;
                     const uint64_t bkey = d->bucket_key[E.table[i].loc & LOC_BUCKET_MASK];
                     if (bkey != (M ? murmur3_h1_bytes(buf, M) : 0ull)) foreign = true;
-                    E.direct[code] = (uint32_t)(E.table[i].loc >> LOC_BUCKET_BITS);
+                    const uint32_t off = (uint32_t)(E.table[i].loc >> LOC_BUCKET_BITS);
+                    const uint32_t n_tips = E.postings[(size_t)off * 4] & POST_LEN_MASK;
+                    uint32_t lg = 0;
+                    while (lg < 31 && (1u << lg) <= n_tips) ++lg;  // bit length: small = specific k-mer
+                    E.direct[2 * code] = off;
+                    E.direct[2 * code + 1] = n_tips ? ((lg << DIRECT_TIP_BITS) | (E.postings[(size_t)off * 4 + 2] & DIRECT_TIP_MASK)) : 0xFFFFFFFFu;
                     ++cnt;
                     break;
                 }

@@ -16,7 +16,7 @@ struct EncodedDb {
     uint32_t format = FMT_LIST;
     bool strictly_binary = false;
     std::vector<uint64_t> bucket_key;
-    std::vector<uint32_t> direct;     // 4^k record offsets (FMT_SPLIT, k <= DIRECT_MAX_K) or empty
+    std::vector<uint32_t> direct;     // 4^k x {record offset, meta} (FMT_SPLIT, k <= DIRECT_MAX_K) or empty
     uint32_t k = 0, m = 0, m_eff = 0;
     uint32_t max_depth = 0, max_nonleaf_arity = 0;
     uint64_t n_kmers = 0, n_closed = 0;

@@ -77,7 +77,11 @@ constexpr uint32_t SPLIT_FIRST_REC = 2;
 // query side needs neither MurmurHash nor a probe loop.  Only built when every
 // index entry sits in the minimizer bucket of its own prefix (true for every
 // `cls build-db` output), which makes the bucket filter of kmers_map.rs:295-297 a no-op.
+// Entry = {record offset (0 = absent), meta}; meta = bit_length(n_tips) << 27 | first tip
+// (0xFFFFFFFF if absent) feeds the locality ordering of cls_kernels.hip (order_key_kernel).
 constexpr uint32_t DIRECT_MAX_K = 15;
+constexpr uint32_t DIRECT_TIP_BITS = 27;
+constexpr uint32_t DIRECT_TIP_MASK = (1u << DIRECT_TIP_BITS) - 1;
 struct TipRec {
     uint32_t tip_prev;  // last tip of the left part
     uint32_t l;         // split of the left part
@@ -93,7 +97,7 @@ struct DbDev {
     const Slot* table;
     const uint32_t* postings;   // FMT_LIST: u32 words; FMT_SPLIT: TipRec records (16-byte units)
     const uint64_t* bucket_key;
-    const uint32_t* direct;     // 4^k entries or nullptr
+    const uint32_t* direct;     // 4^k pairs {offset, meta} or nullptr
     uint64_t table_mask;
     uint32_t n_nodes;
     uint32_t n_buckets;

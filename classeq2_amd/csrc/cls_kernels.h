@@ -9,13 +9,18 @@ namespace cls {
 // Grid sizes + scratch layout of one placement batch.
 struct PlacePlan {
     uint32_t grid[2];          // workgroups per read-length class
+    bool ordered;              // class-0 reads are processed in locality order (fast path, large batches)
+    uint64_t keys_off_words;   // sort keys / indices
+    uint64_t sort_off_words;   // radix-sort scratch
+    size_t sort_bytes;
     uint64_t child_off_words;  // offset of the child-counter area inside the workspace
     uint64_t ws_bytes;         // device scratch the launch needs
 };
 PlacePlan plan_place(const DbDev& db, uint32_t n_reads, uint32_t n_cu, bool stats);
 // Asynchronous on `stream`; all pointers are device pointers; `d_ws` holds plan.ws_bytes.
+// `ev_start`/`ev_stop` (may be null) are recorded around the class-0 placement kernel.
 hipError_t launch_place(const DbDev& db, const PlaceParams& prm, const PlacePlan& plan, const uint8_t* d_bases,
                         const uint64_t* d_offsets, uint32_t n_reads, cls_placement* d_out, cls_query_stats* d_stats,
-                        uint32_t* d_ws, hipStream_t stream);
+                        uint32_t* d_ws, hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop);
 
 }  // namespace cls

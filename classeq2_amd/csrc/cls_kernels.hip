@@ -20,6 +20,7 @@
 #include "cls_device.h"
 #include "cls_kernels.h"
 #include "cls_murmur.h"
+#include "cls_sort.h"
 
 namespace cls {
 
@@ -717,6 +718,65 @@ struct FastCtx {
     uint32_t* set;     // LDS: distinct-hit set keyed by header record offset
 };
 
+// Front of the fast path, shared with order_key_kernel: the read -> LDS (upper-cased, validated),
+// 2 bits per base, then per query k-mer its 2-bit code and the direct-table entry.
+// Returns false if the read holds a character other than ACGT.
+template <int SLOTS, int SET_BITS>
+__device__ __forceinline__ bool fast_front(const DbDev& db, const FastCtx& cx, const uint8_t* __restrict__ bases, uint64_t b0,
+                                           uint32_t L, uint32_t nf, uint32_t nk, uint32_t (&off)[SLOTS], uint32_t (&meta)[SLOTS]) {
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t k = db.k;
+    bool bad = false;
+#pragma unroll 1
+    for (uint32_t i = lane; i < L; i += 64) {
+        uint8_t c = bases[b0 + i];
+        if (c >= 'a' && c <= 'z') c -= 32;
+        bad |= !(c == 'A' || c == 'C' || c == 'G' || c == 'T');
+        cx.ascii[i] = c;
+    }
+#pragma unroll 1
+    for (uint32_t i = lane; i < (1u << SET_BITS); i += 64) cx.set[i] = SET_EMPTY;
+    if (__ballot(bad)) return false;
+    wave_sync();
+    {
+        const uint32_t n_words = (L + 15) >> 4;
+#pragma unroll 1
+        for (uint32_t w = lane; w < n_words; w += 64) {
+            uint32_t acc = 0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {  // 4 ascii bytes -> 8 bits: (c >> 1) & 3 = A0 C1 T2 G3
+                uint32_t t = *reinterpret_cast<const uint32_t*>(cx.ascii + 16 * w + 4 * q);  // reads past L stay inside the buffer
+                t = (t >> 1) & 0x03030303u;
+                t = (t | (t >> 6) | (t >> 12) | (t >> 18)) & 0xFFu;
+                acc |= t << (8 * q);
+            }
+            cx.packed[w] = acc;
+        }
+    }
+    wave_sync();
+    const uint2* __restrict__ direct = reinterpret_cast<const uint2*>(db.direct);
+    const uint32_t kmask = (k == 16) ? 0xFFFFFFFFu : ((1u << (2 * k)) - 1u);
+#pragma unroll
+    for (int s = 0; s < SLOTS; ++s) {
+        const uint32_t j = s * 64 + lane;
+        const bool valid = j < nk;
+        const bool rc = j >= nf;
+        const uint32_t p = valid ? (rc ? (nf - 1) - (j - nf) : j) : 0;  // window start; the rc list runs backwards over the windows
+        const uint32_t w = p >> 4, sh = (2 * p) & 31;
+        const uint32_t d0 = cx.packed[w], d1 = cx.packed[w + 1];
+        uint32_t code = (uint32_t)((((uint64_t)d1 << 32) | d0) >> sh) & kmask;
+        // reverse complement of the window: complement = code ^ 0b10.., then reverse the 2-bit groups
+        uint32_t rcc = __builtin_bitreverse32(code ^ (0xAAAAAAAAu & kmask));
+        rcc = ((rcc >> 1) & 0x55555555u) | ((rcc & 0x55555555u) << 1);
+        rcc >>= (32 - 2 * k);
+        code = rc ? rcc : code;
+        const uint2 e = direct[valid ? code : 0u];
+        off[s] = valid ? e.x : 0u;
+        meta[s] = valid ? e.y : 0xFFFFFFFFu;
+    }
+    return true;
+}
+
 template <int SLOTS, int SET_BITS, bool STATS>
 __device__ __forceinline__ void place_read_fast(const DbDev& db, const PlaceParams& prm, const FastCtx& cx,
                                                 const uint8_t* __restrict__ bases, uint64_t b0, uint64_t b1, uint32_t r,
@@ -735,56 +795,14 @@ __device__ __forceinline__ void place_read_fast(const DbDev& db, const PlacePara
     };
     if (L64 < k) { put_stats(0, 0, 0, 0); write_record(out, r, CLS_ERR_TOO_FEW_KMERS, 0, 0, 0, 0); return; }
     const uint32_t L = (uint32_t)L64, nf = L - k + 1, nk = 2 * nf;  // nk <= 64*SLOTS by classification
-    // ---- A1. load + validate + 2-bit pack --------------------------------------------------------
-    bool bad = false;
-#pragma unroll 1
-    for (uint32_t i = lane; i < L; i += 64) {
-        uint8_t c = bases[b0 + i];
-        if (c >= 'a' && c <= 'z') c -= 32;
-        bad |= !(c == 'A' || c == 'C' || c == 'G' || c == 'T');
-        cx.ascii[i] = c;
+    // ---- A1/A2. load + validate + 2-bit pack; per k-mer: code -> direct table ----------------------
+    uint32_t off[SLOTS], meta[SLOTS];
+    if (!fast_front<SLOTS, SET_BITS>(db, cx, bases, b0, L, nf, nk, off, meta)) {
+        put_stats(0, 0, 0, 0);
+        write_record(out, r, CLS_ERR_INVALID_BASE, 0, 0, 0, 0);
+        return;
     }
-#pragma unroll 1
-    for (uint32_t i = lane; i < (1u << SET_BITS); i += 64) cx.set[i] = SET_EMPTY;
-    if (__ballot(bad)) { put_stats(0, 0, 0, 0); write_record(out, r, CLS_ERR_INVALID_BASE, 0, 0, 0, 0); return; }
-    wave_sync();
-    {
-        const uint32_t n_words = (L + 15) >> 4;
-#pragma unroll 1
-        for (uint32_t w = lane; w < n_words; w += 64) {
-            uint32_t acc = 0;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {  // 4 ascii bytes -> 8 bits: (c >> 1) & 3 = A0 C1 T2 G3
-                uint32_t t = *reinterpret_cast<const uint32_t*>(cx.ascii + 16 * w + 4 * q);  // reads past L stay inside the buffer
-                t = (t >> 1) & 0x03030303u;
-                t = (t | (t >> 6) | (t >> 12) | (t >> 18)) & 0xFFu;
-                acc |= t << (8 * q);
-            }
-            cx.packed[w] = acc;
-        }
-    }
-    wave_sync();
-    // ---- A2. per k-mer: code -> direct table -> distinct set -> header ------------------------------
-    const uint32_t* __restrict__ direct = db.direct;
     const uint4* __restrict__ recs = reinterpret_cast<const uint4*>(db.postings);
-    const uint32_t kmask = (k == 16) ? 0xFFFFFFFFu : ((1u << (2 * k)) - 1u);
-    uint32_t off[SLOTS];
-#pragma unroll
-    for (int s = 0; s < SLOTS; ++s) {
-        const uint32_t j = s * 64 + lane;
-        const bool valid = j < nk;
-        const bool rc = j >= nf;
-        const uint32_t p = valid ? (rc ? (nf - 1) - (j - nf) : j) : 0;  // window start; the rc list runs backwards over the windows
-        const uint32_t w = p >> 4, sh = (2 * p) & 31;
-        const uint32_t d0 = cx.packed[w], d1 = cx.packed[w + 1];
-        uint32_t code = (uint32_t)((((uint64_t)d1 << 32) | d0) >> sh) & kmask;
-        // reverse complement of the window: complement = code ^ 0b10.., then reverse the 2-bit groups
-        uint32_t rcc = __builtin_bitreverse32(code ^ (0xAAAAAAAAu & kmask));
-        rcc = ((rcc >> 1) & 0x55555555u) | ((rcc & 0x55555555u) << 1);
-        rcc >>= (32 - 2 * k);
-        code = rc ? rcc : code;
-        off[s] = valid ? direct[code] : 0u;
-    }
     // distinct hashes: the FIRST k-mer that reaches an entry keeps it (HashSet<u64> semantics)
 #pragma unroll
     for (int s = 0; s < SLOTS; ++s) {
@@ -916,8 +934,8 @@ __device__ __forceinline__ void place_read_fast(const DbDev& db, const PlacePara
 template <int SLOTS, int SET_BITS, bool STATS>
 __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, MIN_WAVES_PER_EU) void place_fast_kernel(
     DbDev db, PlaceParams prm, const uint8_t* __restrict__ bases, const uint64_t* __restrict__ offsets,
-    const uint32_t* __restrict__ list, const uint32_t* __restrict__ list_len, cls_placement* __restrict__ out,
-    cls_query_stats* __restrict__ stats, uint32_t ascii_cap, uint32_t profile_stop) {
+    const uint32_t* __restrict__ list, const uint32_t* __restrict__ list_len, uint32_t list_n, uint32_t xcd_chunks,
+    cls_placement* __restrict__ out, cls_query_stats* __restrict__ stats, uint32_t ascii_cap, uint32_t profile_stop) {
     extern __shared__ __align__(16) uint8_t smem[];
     const uint32_t wave = threadIdx.x >> 6;
     const uint32_t packed_words = (ascii_cap >> 4) + 2;
@@ -926,6 +944,25 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, MIN_WAVES_PER_EU) void place_
     cx.ascii = smem + wave * per_wave;
     cx.packed = reinterpret_cast<uint32_t*>(cx.ascii + ascii_cap);
     cx.set = cx.packed + packed_words;
+    if (xcd_chunks) {
+        // locality-ordered list: XCD x (workgroups with blockIdx % 8 == x share an L2) walks the x-th
+        // eighth of the list front to back, so that reads processed together share cache lines
+        const uint32_t n_list = list_n;
+        const uint32_t xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3, bpx = gridDim.x >> 3;
+        const uint32_t chunk = (n_list + 7u) >> 3;
+        const uint32_t cap = 64 * SLOTS;
+        for (uint32_t ql = slot * WAVES_PER_BLOCK + wave; ql < chunk; ql += bpx * WAVES_PER_BLOCK) {
+            const uint32_t q = xcd * chunk + ql;
+            if (q >= n_list) break;
+            const uint32_t r = list[q];
+            const uint64_t b0 = offsets[r], b1 = offsets[r + 1];
+            const uint64_t L64 = b1 - b0;
+            if (L64 >= db.k && 2 * (L64 - db.k + 1) > cap) continue;  // another class' read (classify_kernel binned it)
+            place_read_fast<SLOTS, SET_BITS, STATS>(db, prm, cx, bases, b0, b1, r, out, stats, profile_stop);
+            wave_sync();
+        }
+        return;
+    }
     const uint32_t gw = blockIdx.x * WAVES_PER_BLOCK + wave;
     const uint32_t n_waves = gridDim.x * WAVES_PER_BLOCK;
     const uint32_t n_list = *list_len;
@@ -934,6 +971,75 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, MIN_WAVES_PER_EU) void place_
         const uint64_t b0 = offsets[r], b1 = offsets[r + 1];
         place_read_fast<SLOTS, SET_BITS, STATS>(db, prm, cx, bases, b0, b1, r, out, stats, profile_stop);
         wave_sync();
+    }
+}
+
+// Locality key of every read for the ordering above: among the read's k-mers present in the index the
+// most specific one (fewest tips; ties: smaller first tip, then smaller record offset) names a leaf
+// neighbourhood (its first tip) and, through its record offset, a group of overlapping reads.
+// Reads the fast kernel will not place (too short / too long / bad characters) get the last key.
+template <int SLOTS>
+__global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void order_key_kernel(DbDev db, const uint8_t* __restrict__ bases,
+                                                                       const uint64_t* __restrict__ offsets, uint32_t n_reads,
+                                                                       uint64_t* __restrict__ keys, uint32_t* __restrict__ idx,
+                                                                       uint32_t ascii_cap, uint32_t tip_bits, uint32_t spec_lg,
+                                                                       uint32_t block_shift) {
+    extern __shared__ __align__(16) uint8_t smem[];
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t packed_words = (ascii_cap >> 4) + 2;
+    const uint32_t per_wave = ascii_cap + 4u * packed_words + 16u;
+    FastCtx cx;
+    cx.ascii = smem + wave * per_wave;
+    cx.packed = reinterpret_cast<uint32_t*>(cx.ascii + ascii_cap);
+    cx.set = cx.packed + packed_words;  // 1 dummy entry (SET_BITS = 0)
+    const uint32_t gw = blockIdx.x * WAVES_PER_BLOCK + wave;
+    const uint32_t n_waves = gridDim.x * WAVES_PER_BLOCK;
+    for (uint32_t r = gw; r < n_reads; r += n_waves) {
+        const uint64_t b0 = offsets[r], L64 = offsets[r + 1] - b0;
+        uint64_t key = ~0ull;
+        if (L64 >= db.k && 2 * (L64 - db.k + 1) <= (uint64_t)(64 * SLOTS)) {
+            const uint32_t L = (uint32_t)L64, nf = L - db.k + 1, nk = 2 * nf;
+            uint32_t off[SLOTS], meta[SLOTS];
+            if (fast_front<SLOTS, 0>(db, cx, bases, b0, L, nf, nk, off, meta)) {
+                // candidates: k-mers present in the index that are specific to a small clade (few tips);
+                // the tip bound is widened until a handful qualify (finally: every k-mer present)
+                uint32_t cand = 0, n_cand = 0;
+                uint32_t lg_max = spec_lg;
+                for (int tier = 0; tier < 4 && n_cand < 4; ++tier, lg_max = tier == 3 ? 31u : lg_max + 3u) {
+                    cand = 0; n_cand = 0;
+#pragma unroll
+                    for (int s = 0; s < SLOTS; ++s) {
+                        const bool c = off[s] != 0 && (meta[s] >> DIRECT_TIP_BITS) <= lg_max;
+                        cand |= (c ? 1u : 0u) << s;
+                        n_cand += popc64(__ballot(c));
+                    }
+                }
+                if (n_cand) {
+                    // median first tip of the candidates (robust against the chance matches of sequencing
+                    // errors, which land anywhere in the tree): radix select, one bit per round
+                    uint32_t rank = n_cand >> 1, prefix = 0;
+                    for (int bit = (int)tip_bits - 1; bit >= 0; --bit) {
+                        uint32_t c0 = 0;
+#pragma unroll
+                        for (int s = 0; s < SLOTS; ++s) {
+                            const uint32_t t = meta[s] & DIRECT_TIP_MASK;
+                            const bool z = ((cand >> s) & 1u) && ((t ^ prefix) >> (bit + 1)) == 0 && !((t >> bit) & 1u);
+                            c0 += popc64(__ballot(z));
+                        }
+                        if (rank >= c0) { rank -= c0; prefix |= 1u << bit; }
+                    }
+                    // group of overlapping reads: the smallest record offset among the candidates (MinHash-like:
+                    // reads that share most of their specific k-mers share it)
+                    uint32_t mh = 0xFFFFFFFFu;
+#pragma unroll
+                    for (int s = 0; s < SLOTS; ++s) if ((cand >> s) & 1u) mh = off[s] < mh ? off[s] : mh;
+                    for (int o = 32; o > 0; o >>= 1) { const uint32_t other = __shfl_xor(mh, o); mh = other < mh ? other : mh; }
+                    key = ((uint64_t)(prefix >> block_shift) << 32) | mh;
+                }
+            }
+            wave_sync();
+        }
+        if (lane == 0) { keys[r] = key; idx[r] = r; }
     }
 }
 
@@ -977,9 +1083,14 @@ __global__ void classify_kernel(const uint64_t* __restrict__ offsets, uint32_t n
 
 namespace {
 constexpr int N_CLASSES = 2;
+constexpr int ORDER_KEY_BITS = 32 + DIRECT_TIP_BITS;  // {first tip, record offset}
 constexpr int CLS_SLOTS[N_CLASSES] = {5, 16};      // k-mers per read: 320 / 1024
 constexpr int CLS_SET_BITS[N_CLASSES] = {9, 11};   // LDS distinct-hit set: 512 / 2048 entries
 
+bool use_order(const DbDev& db, uint32_t n_reads) {
+    static const bool off = getenv("CLS_NO_ORDER") != nullptr;  // A/B experiments
+    return db.format == FMT_SPLIT && db.direct != nullptr && getenv("CLS_NO_FAST") == nullptr && !off && n_reads >= 4096;
+}
 bool use_fast(const DbDev& db) {
     static const bool off = getenv("CLS_NO_FAST") != nullptr;  // A/B experiments
     return db.format == FMT_SPLIT && db.direct != nullptr && !off;
@@ -1035,15 +1146,26 @@ PlacePlan plan_place(const DbDev& db, uint32_t n_reads, uint32_t n_cu, bool stat
         p.grid[c] = want < cap ? (want ? want : 1) : cap;
         child_words = std::max<uint64_t>(child_words, (uint64_t)p.grid[c] * WAVES_PER_BLOCK * 2 * child_ws_stride(db));
     }
-    // workspace: [counts: 16 words][list0: n][list1: n][child counters]
-    p.child_off_words = 16 + 2 * (uint64_t)n_reads;
+    // workspace (u32 words): [counts 16][list0 n][list1 n][keys_in 2n][keys_out 2n][idx_in n][idx_out n][sort temp][child counters]
+    p.ordered = use_order(db, n_reads);
+    uint64_t w = 16 + 2 * (uint64_t)n_reads;
+    if (p.ordered) {
+        p.grid[0] = std::max<uint32_t>(8, p.grid[0] & ~7u);  // whole octets of workgroups: one slice of the list per XCD
+        p.keys_off_words = w;
+        w += 6 * (uint64_t)n_reads;
+        p.sort_off_words = w;
+        p.sort_bytes = sort_temp_bytes(n_reads, ORDER_KEY_BITS);
+        w += (p.sort_bytes + 3) / 4 + 2;
+        w += w & 1;
+    }
+    p.child_off_words = w;
     p.ws_bytes = (p.child_off_words + child_words) * 4;
     return p;
 }
 
 hipError_t launch_place(const DbDev& db, const PlaceParams& prm, const PlacePlan& plan, const uint8_t* d_bases,
                         const uint64_t* d_offsets, uint32_t n_reads, cls_placement* d_out, cls_query_stats* d_stats,
-                        uint32_t* d_ws, hipStream_t stream) {
+                        uint32_t* d_ws, hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop) {
     if (n_reads == 0) return hipSuccess;
     uint32_t* counts = d_ws;
     uint32_t* lists[N_CLASSES] = {d_ws + 16, d_ws + 16 + n_reads};
@@ -1058,6 +1180,27 @@ hipError_t launch_place(const DbDev& db, const PlaceParams& prm, const PlacePlan
     const uint32_t ws_stride = child_ws_stride(db);
     const bool st = d_stats != nullptr;
     const bool binary = db.max_nonleaf_arity <= 2;
+    const uint32_t* list0 = lists[0];
+    uint32_t list0_n = 0, xcd_chunks = 0;
+    if (plan.ordered) {
+        uint64_t* keys_in = reinterpret_cast<uint64_t*>(d_ws + plan.keys_off_words);
+        uint64_t* keys_out = keys_in + n_reads;
+        uint32_t* idx_in = reinterpret_cast<uint32_t*>(keys_out + n_reads);
+        uint32_t* idx_out = idx_in + n_reads;
+        const uint32_t ac = ascii_cap_of(db, 0);
+        uint32_t tip_bits = 1;
+        while (tip_bits < 32 && (1u << tip_bits) < db.n_nodes) ++tip_bits;
+        static const uint32_t spec_lg = [] { const char* v = getenv("CLS_ORDER_SPEC_LG"); return v ? (uint32_t)atoi(v) : 3u; }();
+        static const uint32_t block_shift = [] { const char* v = getenv("CLS_ORDER_BLOCK_SHIFT"); return v ? (uint32_t)atoi(v) : 2u; }();
+        const size_t smem_k = (size_t)WAVES_PER_BLOCK * (ac + 4u * ((ac >> 4) + 2) + 16u);
+        hipLaunchKernelGGL((order_key_kernel<CLS_SLOTS[0]>), dim3(plan.grid[0]), dim3(64 * WAVES_PER_BLOCK), smem_k, stream, db, d_bases,
+                           d_offsets, n_reads, keys_in, idx_in, ac, tip_bits, spec_lg, block_shift);
+        e = sort_pairs(d_ws + plan.sort_off_words, plan.sort_bytes, keys_in, keys_out, idx_in, idx_out, n_reads, ORDER_KEY_BITS, stream);
+        if (e != hipSuccess) return e;
+        list0 = idx_out;
+        list0_n = n_reads;
+        xcd_chunks = 1;
+    }
     auto launch_class = [&](auto slots_c, auto bits_c, int c) {
         constexpr int SLOTS = decltype(slots_c)::value, SET_BITS = decltype(bits_c)::value;
         const dim3 grid(plan.grid[c]), block(64 * WAVES_PER_BLOCK);
@@ -1065,10 +1208,12 @@ hipError_t launch_place(const DbDev& db, const PlaceParams& prm, const PlacePlan
         const size_t smem = smem_of(db, c);
         if (use_fast(db)) {
             const uint32_t ac = ascii_cap_of(db, c);
+            const uint32_t* lst = c == 0 ? list0 : lists[c];
+            const uint32_t ln = c == 0 ? list0_n : 0u, xc = c == 0 ? xcd_chunks : 0u;
             if (st) hipLaunchKernelGGL((place_fast_kernel<SLOTS, SET_BITS, true>), grid, block, smem, stream, db, prm, d_bases, d_offsets,
-                                       lists[c], counts + c, d_out, d_stats, ac, profile_stop);
+                                       lst, counts + c, ln, xc, d_out, d_stats, ac, profile_stop);
             else hipLaunchKernelGGL((place_fast_kernel<SLOTS, SET_BITS, false>), grid, block, smem, stream, db, prm, d_bases, d_offsets,
-                                    lists[c], counts + c, d_out, d_stats, ac, profile_stop);
+                                    lst, counts + c, ln, xc, d_out, d_stats, ac, profile_stop);
             return;
         }
         if (db.format == FMT_SPLIT) {
@@ -1085,7 +1230,9 @@ hipError_t launch_place(const DbDev& db, const PlaceParams& prm, const PlacePlan
         else { if (binary) CLS_LAUNCH(false, true); else CLS_LAUNCH(false, false); }
 #undef CLS_LAUNCH
     };
+    if (ev_start) (void)hipEventRecord(ev_start, stream);
     launch_class(std::integral_constant<int, CLS_SLOTS[0]>{}, std::integral_constant<int, CLS_SET_BITS[0]>{}, 0);
+    if (ev_stop) (void)hipEventRecord(ev_stop, stream);
     if (hipGetLastError() != hipSuccess) return hipErrorLaunchFailure;
     launch_class(std::integral_constant<int, CLS_SLOTS[1]>{}, std::integral_constant<int, CLS_SET_BITS[1]>{}, 1);
     return hipGetLastError();

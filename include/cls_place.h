@@ -197,6 +197,13 @@ int cls_place_batch(cls_db* db, const char* bases, const uint64_t* offsets, uint
 int cls_place_batch_device(cls_db* db, const void* d_bases, const void* d_offsets, uint32_t n,
                            const cls_params* params, void* d_out, void* d_stats, void* hip_stream);
 
+/* Device time of the DOMINANT placement kernel (the per-read placement kernel of the
+ * 320-k-mer class), accumulated over every cls_place_batch_device() launch on this
+ * handle since the last reset: HIP events recorded around that kernel on the
+ * caller's stream.  Waits for the launches still in flight.  Measurement aid for
+ * bench.py's roofline figure; `reset` != 0 clears the accumulators afterwards. */
+int cls_db_kernel_time(cls_db* db, double* sum_ms, uint64_t* launches, int reset);
+
 /* Host-buffer variant that also returns the per-query counters. */
 int cls_place_batch_stats(cls_db* db, const char* bases, const uint64_t* offsets, uint32_t n,
                           const cls_params* params, cls_placement* out, cls_query_stats* stats);
