@@ -25,6 +25,11 @@ EXPORTS = [
     "cls_place_batch_device", "cls_place_batch_stats", "cls_fasta_parse", "cls_fasta_free", "cls_last_error",
     "cls_version",
 ]
+HOST_EXPORTS = [
+    "cls_tree_load_json", "cls_tree_free", "cls_tree_set_annotations_yaml", "cls_tree_desc", "cls_serialize_results",
+    "cls_host_free", "cls_place_sequences", "cls_host_last_error",
+]
+FORMAT_YAML, FORMAT_JSONL = 0, 1
 
 
 class ClsError(RuntimeError):
@@ -67,6 +72,24 @@ def lib():
         L.cls_fasta_free.restype = None
         L.cls_last_error.restype = C.c_char_p
         L.cls_version.restype = C.c_char_p
+        # host-side mirror (include/cls_host.h)
+        L.cls_tree_load_json.argtypes = [C.c_char_p, C.POINTER(vp)]
+        L.cls_tree_load_json.restype = i32
+        L.cls_tree_free.argtypes = [vp]
+        L.cls_tree_free.restype = None
+        L.cls_tree_set_annotations_yaml.argtypes = [vp, C.c_char_p]
+        L.cls_tree_set_annotations_yaml.restype = i32
+        L.cls_tree_desc.argtypes = [vp, C.POINTER(_abi.DbDesc)]
+        L.cls_tree_desc.restype = i32
+        L.cls_serialize_results.argtypes = [vp, C.c_char_p, vp, u32, vp, i32, C.POINTER(vp), C.POINTER(C.c_size_t),
+                                            C.POINTER(vp), C.POINTER(C.c_size_t)]
+        L.cls_serialize_results.restype = i32
+        L.cls_host_free.argtypes = [vp]
+        L.cls_host_free.restype = None
+        L.cls_place_sequences.argtypes = [vp, vp, C.c_char_p, C.c_char_p, C.POINTER(_abi.Params), i32, i32,
+                                          C.POINTER(u32), C.POINTER(C.c_double)]
+        L.cls_place_sequences.restype = i32
+        L.cls_host_last_error.restype = C.c_char_p
         _LIB = L
     return _LIB
 
@@ -172,3 +195,60 @@ class PlacementDb:
         """Device pointers in/out, asynchronous on `stream` (cls_place_batch_device)."""
         pp = C.byref(params) if params is not None else None
         _check(lib().cls_place_batch_device(self._h, d_bases, d_offsets, n, pp, d_out, d_stats or None, stream or None))
+
+
+def _check_host(rc: int):
+    if rc != 0:
+        msg = lib().cls_host_last_error().decode(errors="replace") or lib().cls_last_error().decode(errors="replace")
+        raise ClsError(rc, msg)
+
+
+class Tree:
+    """cls_tree: the reference's database / tree JSON export + optional annotations (include/cls_host.h)."""
+
+    def __init__(self, json_path: str, annotations_yaml: Optional[str] = None):
+        self._h = C.c_void_p()
+        _check_host(lib().cls_tree_load_json(json_path.encode(), C.byref(self._h)))
+        if annotations_yaml:
+            _check_host(lib().cls_tree_set_annotations_yaml(self._h, annotations_yaml.encode()))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().cls_tree_free(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def flat(self) -> FlatDb:
+        d = _abi.DbDesc()
+        _check_host(lib().cls_tree_desc(self._h, C.byref(d)))
+        return FlatDb.from_desc(d, keepalive=self)
+
+    def serialize(self, headers, records: np.ndarray, fmt: int = FORMAT_YAML):
+        """-> (result text, error text) exactly as `place_sequences` would append them to its two files."""
+        hb = [h if isinstance(h, bytes) else h.encode() for h in headers]
+        off = np.concatenate([[0], np.cumsum([len(h) for h in hb])]).astype(np.uint64)
+        recs = np.ascontiguousarray(records, dtype=_abi.PLACEMENT_DTYPE)
+        out, err = C.c_void_p(), C.c_void_p()
+        ol, el = C.c_size_t(0), C.c_size_t(0)
+        _check_host(lib().cls_serialize_results(self._h, b"".join(hb), off.ctypes.data, len(hb), recs.ctypes.data, fmt,
+                                                C.byref(out), C.byref(ol), C.byref(err), C.byref(el)))
+        try:
+            return C.string_at(out, ol.value), C.string_at(err, el.value)
+        finally:
+            lib().cls_host_free(out)
+            lib().cls_host_free(err)
+
+
+def place_sequences(db: "PlacementDb", tree: Tree, query_path: str, out_file: str, params: Optional[_abi.Params] = None,
+                    overwrite: bool = False, fmt: int = FORMAT_YAML):
+    """The whole use-case (mod.rs:43-270) through cls_place_sequences: -> (records read, seconds)."""
+    n, sec = C.c_uint32(0), C.c_double(0)
+    _check_host(lib().cls_place_sequences(db._h, tree._h, query_path.encode(), out_file.encode(),
+                                          C.byref(params) if params is not None else None, 1 if overwrite else 0, fmt,
+                                          C.byref(n), C.byref(sec)))
+    return n.value, sec.value

@@ -1,0 +1,54 @@
+/*
+ * cls_host.h -- host-side mirror of the reference's batch driver (part of libclsplace.so).
+ *
+ * The reference's `place_sequences` (core/src/use_cases/place_sequences/mod.rs:43-270) reads a
+ * multi-FASTA, places every record and appends one YAML document or JSON line per record to
+ * `<out>.yaml|.jsonl`, per-query errors to `<out>.error`.  These entry points do the same above the
+ * GPU path, for callers that do not keep the Rust front-end (the C++ `cls-place` tool in csrc/ is one).
+ * Tree / index / annotations come from the reference's own file formats:
+ *   - database: the JSON export of `cls convert database -f json` (ports/cli/src/cmds/convert.rs:161-205);
+ *   - annotations: the YAML list of `Annotation` (core/src/domain/dtos/annotation.rs:25-34).
+ */
+#ifndef CLS_HOST_H
+#define CLS_HOST_H
+
+#include "cls_place.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct cls_tree cls_tree; /* Tree: root clade (+ names, supports, lengths), annotations, k-mer map */
+
+enum { CLS_FORMAT_YAML = 0, CLS_FORMAT_JSONL = 1 }; /* OutputFormat, core/src/domain/dtos/output_format.rs:3-11 */
+
+/* Parse a database (or `--only-tree`) JSON export.  Replaces load_database
+ * (ports/lib/src/functions/load_database.rs:9-53) for the JSON form. */
+int cls_tree_load_json(const char* path, cls_tree** out);
+void cls_tree_free(cls_tree* t);
+/* `-a/--annotations-file-path` of `cls place` (ports/cli/src/cmds/place_sequences.rs:137-144). */
+int cls_tree_set_annotations_yaml(cls_tree* t, const char* path);
+/* Borrowed flat view for cls_db_create(); valid while `t` lives. */
+int cls_tree_desc(const cls_tree* t, cls_db_desc* d);
+
+/* PlacementResponse serialisation (mod.rs:170-248, placement_response.rs:30-94): one YAML document
+ * ("---\n" + mapping) or one JSON line per non-error record, in input order; the messages of error
+ * records concatenated as the reference appends them to `<out>.error`.  Buffers are malloc'ed; release
+ * them with cls_host_free().  `err_text` may be NULL. */
+int cls_serialize_results(const cls_tree* t, const char* headers, const uint64_t* header_off, uint32_t n,
+                          const cls_placement* recs, int format, char** out_text, size_t* out_len,
+                          char** err_text, size_t* err_len);
+void cls_host_free(void* p);
+
+/* The whole use-case: FASTA (`query_path`, "-" = stdin) -> placements on the GPU -> result + error files.
+ * `out_file` gets its extension replaced like PathBuf::set_extension (mod.rs:76-81); `overwrite` is
+ * `--force-overwrite`.  Returns the number of records read and the UCPLACE0001->0002 wall time. */
+int cls_place_sequences(cls_db* db, const cls_tree* t, const char* query_path, const char* out_file,
+                        const cls_params* params, int overwrite, int format, uint32_t* n_placed, double* seconds);
+
+const char* cls_host_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

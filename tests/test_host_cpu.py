@@ -17,12 +17,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_header_symbols_exported():
-    hdr = open(os.path.join(ROOT, "include", "cls_place.h")).read()
-    declared = set(re.findall(r"^(?:int|void|const char\*)\s+(cls_[a-z_]+)\(", hdr, flags=re.M))
-    assert declared == set(engine.EXPORTS), declared ^ set(engine.EXPORTS)
     L = engine.lib()
-    for name in declared:
-        assert hasattr(L, name), name
+    for header, exports in (("cls_place.h", engine.EXPORTS), ("cls_host.h", engine.HOST_EXPORTS)):
+        hdr = open(os.path.join(ROOT, "include", header)).read()
+        declared = set(re.findall(r"^(?:int|void|const char\*)\s+(cls_[a-z0-9_]+)\(", hdr, flags=re.M))
+        assert declared == set(exports), (header, declared ^ set(exports))
+        for name in declared:
+            assert hasattr(L, name), name
     assert b"gfx950" in L.cls_version()
 
 
