@@ -116,6 +116,6 @@ struct PlaceParams {
 
 // Per-read k-mer capacity of the widest kernel (reads beyond it are reported
 // as CLS_ERR_READ_TOO_LONG).
-constexpr uint32_t MAX_READ_KMERS = 64 * 16;
+constexpr uint32_t MAX_READ_KMERS = 64 * 8 * 16;
 
 }  // namespace cls

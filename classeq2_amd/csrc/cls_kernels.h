@@ -8,7 +8,8 @@ namespace cls {
 
 // Grid sizes + scratch layout of one placement batch.
 struct PlacePlan {
-    uint32_t grid[2];          // workgroups per read-length class
+    uint32_t grid[2];          // workgroups per wave-per-read class
+    uint32_t grid_blk;         // workgroups of the workgroup-per-read class
     bool ordered;              // class-0 reads are processed in locality order (fast path, large batches)
     uint64_t keys_off_words;   // sort keys / indices
     uint64_t sort_off_words;   // radix-sort scratch

@@ -159,6 +159,7 @@ struct WaveCtx {
     uint32_t* ent;   // LDS: per k-mer, postings offset of its (first-seen) hit or SET_EMPTY
     uint32_t* cnt;   // general path: |K_c| per non-LEAF child
     uint32_t* only;  // general path: |K_c \ R_c| per non-LEAF child
+    uint32_t* red;   // LDS: 3 x 4 words for the cross-wave sums of a multi-wave group (unused when one wave places a read)
 };
 
 __device__ __forceinline__ void write_record(cls_placement* out, uint32_t r, uint32_t status, int32_t one, int32_t rest,
@@ -171,15 +172,42 @@ __device__ __forceinline__ void write_record(cls_placement* out, uint32_t r, uin
     }
 }
 
+// ---- group = the WAVES wavefronts that place one read together (1: a wavefront; >1: the workgroup) ----
+template <int WAVES> __device__ __forceinline__ void grp_sync() { if constexpr (WAVES == 1) wave_sync(); else __syncthreads(); }
+template <int WAVES> __device__ __forceinline__ bool grp_any(bool p) {
+    if constexpr (WAVES == 1) return __ballot(p) != 0; else return __syncthreads_or(p ? 1 : 0) != 0;
+}
+// Sum over the group of up to 4 per-wave values (each wave passes its own partial sums).  `red` = 3
+// rotating LDS buffers of 4 words, `round` a counter every thread of the group advances identically:
+// one barrier per call (the buffer two rounds ahead is cleared while nobody can still be reading it).
+template <int WAVES>
+__device__ __forceinline__ void grp_sum4(uint32_t (&v)[4], uint32_t* red, uint32_t& round) {
+    if constexpr (WAVES > 1) {
+        uint32_t* cur = red + 4 * (round % 3), *nxt = red + 4 * ((round + 1) % 3);
+        if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) if (v[i]) atomicAdd(&cur[i], v[i]);
+        }
+        if (threadIdx.x < 4) nxt[threadIdx.x] = 0;
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = cur[i];
+        ++round;
+    }
+}
+
 // Phases A0-A2 for one read, shared by both postings formats.  Returns false when the
 // read's record has already been written (error statuses); otherwise cx.ent[j] holds, for
 // query k-mer j < nk, the postings offset of its index entry if j is the FIRST query k-mer
 // with that hash and the entry passes the minimizer-bucket filter, else SET_EMPTY.
-template <int SLOTS, int SET_BITS, bool STATS>
+template <int SLOTS, int SET_BITS, bool STATS, int WAVES = 1>
 __device__ __forceinline__ bool match_phase(const DbDev& db, const WaveCtx& cx, const uint8_t* __restrict__ bases,
                                             uint64_t b0, uint64_t b1, uint32_t r, cls_placement* __restrict__ out,
                                             cls_query_stats* __restrict__ stats, uint32_t& nk_out) {
     const uint32_t lane = threadIdx.x & 63;
+    constexpr uint32_t GS = 64 * WAVES;                       // threads that share the read
+    const uint32_t tid = WAVES == 1 ? lane : threadIdx.x;
+    (void)tid;
     const uint32_t k = db.k;
     const uint64_t L64 = b1 - b0;
     auto put_stats = [&](uint32_t nk, uint32_t nm, uint32_t nr, uint64_t lp) {
@@ -197,7 +225,7 @@ __device__ __forceinline__ bool match_phase(const DbDev& db, const WaveCtx& cx, 
         return false;
     }
     const uint64_t nk64 = 2 * (L64 - k + 1);
-    if (nk64 > (uint64_t)(64 * SLOTS)) {
+    if (nk64 > (uint64_t)(GS * SLOTS)) {
         put_stats(nk64 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)nk64, 0, 0, 0);
         write_record(out, r, CLS_ERR_READ_TOO_LONG, 0, 0, 0, 0);
         return false;
@@ -207,9 +235,10 @@ __device__ __forceinline__ bool match_phase(const DbDev& db, const WaveCtx& cx, 
     // LDS holds the forward string followed by its reverse complement, so that query k-mer j
     // (forward ones first, then those of the reverse complement, kmers_map.rs:387-395) is the
     // k contiguous bytes at kmer_start(j).
+    if (WAVES > 1 && tid < 12) cx.red[tid] = 0;
     bool bad = false;
 #pragma unroll 1
-    for (uint32_t i = lane; i < L; i += 64) {
+    for (uint32_t i = tid; i < L; i += GS) {
         uint8_t c = bases[b0 + i];
         if (c >= 'a' && c <= 'z') c -= 32;
         bad |= !(c == 'A' || c == 'C' || c == 'G' || c == 'T');
@@ -217,13 +246,13 @@ __device__ __forceinline__ bool match_phase(const DbDev& db, const WaveCtx& cx, 
         cx.seq[2 * L - 1 - i] = c ^ ((c & 2) ? 0x04 : 0x15);  // A<->T, C<->G
     }
 #pragma unroll 1
-    for (uint32_t i = lane; i < (1u << SET_BITS); i += 64) cx.set[i] = SET_EMPTY;
-    if (__ballot(bad)) {
+    for (uint32_t i = tid; i < (1u << SET_BITS); i += GS) cx.set[i] = SET_EMPTY;
+    if (grp_any<WAVES>(bad)) {
         put_stats(0, 0, 0, 0);  // the reference dies inside build_kmer_from_string, before any count exists
         write_record(out, r, CLS_ERR_INVALID_BASE, 0, 0, 0, 0);
         return false;
     }
-    wave_sync();
+    grp_sync<WAVES>();
     // ---- A2. hash every k-mer + its minimizer prefix, probe the table, apply the
     // minimizer-bucket filter and the distinct-hash de-duplication; one k-mer per
     // (slot, lane); the surviving postings offsets are staged in LDS (cx.ent).
@@ -231,8 +260,8 @@ __device__ __forceinline__ bool match_phase(const DbDev& db, const WaveCtx& cx, 
     const uint32_t m_eff = db.m_eff;
     auto kmer_start = [&](uint32_t j) -> const uint8_t* { return seq + (j < nf ? j : L + (j - nf)); };
 #pragma unroll 1
-    for (uint32_t base = 0; base < nk; base += 64) {
-        const uint32_t j = base + lane;
+    for (uint32_t base = 0; base < nk; base += GS) {
+        const uint32_t j = base + tid;
         bool hit = false;
         uint32_t tidx = 0;
         uint64_t loc = 0, mz = 0;
@@ -278,20 +307,23 @@ __device__ __forceinline__ bool match_phase(const DbDev& db, const WaveCtx& cx, 
                 pos = (pos + 1) & ((1u << SET_BITS) - 1);
             }
         }
-        cx.ent[j] = ent;  // j < 64*SLOTS always
+        cx.ent[j] = ent;  // j < GS*SLOTS always
     }
-    wave_sync();
+    grp_sync<WAVES>();
     nk_out = nk;
     return true;
 }
 
-template <int SLOTS, int SET_BITS, bool STATS, bool BINARY>
+template <int SLOTS, int SET_BITS, bool STATS, bool BINARY, int WAVES = 1>
 __device__ __forceinline__ void place_read(const DbDev db, const PlaceParams prm, const WaveCtx cx, const uint8_t* __restrict__ bases,
                            uint64_t b0, uint64_t b1, uint32_t r, cls_placement* __restrict__ out,
                            cls_query_stats* __restrict__ stats) {
     const uint32_t lane = threadIdx.x & 63;
+    constexpr uint32_t GS = 64 * WAVES;                       // threads that share the read
+    const uint32_t tid = WAVES == 1 ? lane : threadIdx.x;
+    (void)tid;
     uint32_t nk = 0;
-    if (!match_phase<SLOTS, SET_BITS, STATS>(db, cx, bases, b0, b1, r, out, stats, nk)) return;
+    if (!match_phase<SLOTS, SET_BITS, STATS, WAVES>(db, cx, bases, b0, b1, r, out, stats, nk)) return;
     auto put_stats = [&](uint32_t nk_, uint32_t nm, uint32_t nr, uint64_t lp) {
         if (STATS && stats && lane == 0) {
             uint64_t* s = reinterpret_cast<uint64_t*>(stats + r);
@@ -308,7 +340,7 @@ __device__ __forceinline__ void place_read(const DbDev db, const PlaceParams prm
     uint32_t act = 0, closedm = 0;
 #pragma unroll
     for (int s = 0; s < SLOTS; ++s) {
-        const uint32_t j = s * 64 + lane;
+        const uint32_t j = s * GS + tid;
         const uint32_t off = (j < nk) ? cx.ent[j] : SET_EMPTY;
         const bool is_new = off != SET_EMPTY;
         bool has_root = false;
@@ -330,10 +362,15 @@ __device__ __forceinline__ void place_read(const DbDev db, const PlaceParams prm
         n_m += popc64(__ballot(is_new));
         n_root += popc64(__ballot(is_new && has_root));
     }
-    if (STATS) {
-        for (int o = 32; o > 0; o >>= 1) leafp += ((uint64_t)__shfl_xor((uint32_t)(leafp >> 32), o) << 32) | __shfl_xor((uint32_t)leafp, o);
-        put_stats(nk, n_m, n_root, leafp);
+    uint32_t rnd = 0;  // grp_sum4 rounds (identical in every thread of the group)
+    if (STATS) for (int o = 32; o > 0; o >>= 1) leafp += ((uint64_t)__shfl_xor((uint32_t)(leafp >> 32), o) << 32) | __shfl_xor((uint32_t)leafp, o);
+    {
+        uint32_t v[4] = {n_m, n_root, STATS ? (uint32_t)leafp : 0u, STATS ? (uint32_t)(leafp >> 32) : 0u};
+        grp_sum4<WAVES>(v, cx.red, rnd);
+        n_m = v[0]; n_root = v[1];
+        if (WAVES > 1) leafp = ((uint64_t)v[3] << 32) + v[2];  // (per-wave low words summed: < 2^32 in practice)
     }
+    if (STATS) put_stats(nk, n_m, n_root, leafp);
     // ---- B. thresholds -----------------------------------------------------------------
     if (n_m == 0) { write_record(out, r, CLS_UNCLASSIFIABLE_NO_MATCH, 0, 0, 0, 0); return; }      // :130-139
     if (n_root == 0) { write_record(out, r, CLS_UNCLASSIFIABLE_NO_ROOT, 0, 0, 0, 0); return; }     // :156-164
@@ -375,6 +412,7 @@ __device__ __forceinline__ void place_read(const DbDev db, const PlaceParams prm
                     both += popc64(__ballot(ina && inb));
                 }
             }
+            { uint32_t v[4] = {cnt_a, cnt_b, both, 0}; grp_sum4<WAVES>(v, cx.red, rnd); cnt_a = v[0]; cnt_b = v[1]; both = v[2]; }
             const uint32_t U = cnt_a + cnt_b - both;
             // (one, rest), place_sequence.rs:369-395, with |R_c| = |U| - |only_c| and |R_c \ K_c| = |U| - |K_c|
             for (int c = 0; c < 2; ++c) {
@@ -392,7 +430,11 @@ __device__ __forceinline__ void place_read(const DbDev db, const PlaceParams prm
             }
         } else if (!BINARY) {
             // ---- general path (polytomies): per-child counters in memory --------------------
-            for (uint32_t i = lane; i < m; i += 64) __hip_atomic_store(&cx.only[i], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (uint32_t i = tid; i < m; i += GS) {
+                __hip_atomic_store(&cx.only[i], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (WAVES > 1) __hip_atomic_store(&cx.cnt[i], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (WAVES > 1) { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent"); __syncthreads(); }
             uint32_t nin[SLOTS], which[SLOTS];
 #pragma unroll
             for (int s = 0; s < SLOTS; ++s) { nin[s] = 0; which[s] = 0; }
@@ -407,7 +449,10 @@ __device__ __forceinline__ void place_read(const DbDev db, const PlaceParams prm
                     if (in) { if (nin[s] == 0) which[s] = ci; if (nin[s] < 2) ++nin[s]; }
                     cn += popc64(__ballot(in));
                 }
-                if (lane == 0) __hip_atomic_store(&cx.cnt[ci], cn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (lane == 0) {
+                    if (WAVES == 1) __hip_atomic_store(&cx.cnt[ci], cn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    else if (cn) __hip_atomic_fetch_add(&cx.cnt[ci], cn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
             }
             uint32_t U = 0;
 #pragma unroll
@@ -415,8 +460,9 @@ __device__ __forceinline__ void place_read(const DbDev db, const PlaceParams prm
                 U += popc64(__ballot(nin[s] >= 1));
                 if (nin[s] == 1) __hip_atomic_fetch_add(&cx.only[which[s]], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
+            { uint32_t v[4] = {U, 0, 0, 0}; grp_sum4<WAVES>(v, cx.red, rnd); U = v[0]; }
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
-            wave_sync();
+            grp_sync<WAVES>();
             for (uint32_t base = 0; base < m; base += 64) {
                 const uint32_t ci = base + lane;
                 bool pass = false;
@@ -441,7 +487,7 @@ __device__ __forceinline__ void place_read(const DbDev db, const PlaceParams prm
                     pm &= pm - 1;
                 }
             }
-            wave_sync();
+            grp_sync<WAVES>();
         }
         // ---- PHASE 2 (place_sequence.rs:436-600) -------------------------------------------
         if (n_pass == 0) {
@@ -491,14 +537,17 @@ __device__ __forceinline__ void place_read(const DbDev db, const PlaceParams prm
 // ---- FMT_SPLIT: every node set closed, every clade has 0 or 2 children ---------------------
 // Per k-mer only (vlo, vhi, x) live in registers: the smallest / largest tip inside the current
 // clade and the record index of the split that parts them at their LCA (cls_device.h).
-template <int SLOTS, int SET_BITS, bool STATS>
+template <int SLOTS, int SET_BITS, bool STATS, int WAVES = 1>
 __device__ __forceinline__ void place_read_split(const DbDev db, const PlaceParams prm, const WaveCtx cx,
                                                  const uint8_t* __restrict__ bases, uint64_t b0, uint64_t b1, uint32_t r,
                                                  cls_placement* __restrict__ out, cls_query_stats* __restrict__ stats,
                                                  uint32_t profile_stop) {
     const uint32_t lane = threadIdx.x & 63;
+    constexpr uint32_t GS = 64 * WAVES;                       // threads that share the read
+    const uint32_t tid = WAVES == 1 ? lane : threadIdx.x;
+    (void)tid;
     uint32_t nk = 0;
-    if (!match_phase<SLOTS, SET_BITS, STATS>(db, cx, bases, b0, b1, r, out, stats, nk)) return;
+    if (!match_phase<SLOTS, SET_BITS, STATS, WAVES>(db, cx, bases, b0, b1, r, out, stats, nk)) return;
     if (profile_stop == 1) { write_record(out, r, 0xFE, (int32_t)cx.ent[lane], 0, 0, 0); return; }  // profiling aid only
     const uint4* __restrict__ recs = reinterpret_cast<const uint4*>(db.postings);
     uint32_t vlo[SLOTS], vhi[SLOTS], x[SLOTS];
@@ -506,7 +555,7 @@ __device__ __forceinline__ void place_read_split(const DbDev db, const PlacePara
     uint64_t leafp = 0;
 #pragma unroll
     for (int s = 0; s < SLOTS; ++s) {
-        const uint32_t j = s * 64 + lane;
+        const uint32_t j = s * GS + tid;
         const uint32_t off = (j < nk) ? cx.ent[j] : SET_EMPTY;
         const bool is_new = off != SET_EMPTY;
         const uint4 hd = recs[is_new ? off : 0u];  // {n | flags, root split, first tip, last tip}
@@ -519,14 +568,19 @@ __device__ __forceinline__ void place_read_split(const DbDev db, const PlacePara
         n_m += popc64(__ballot(is_new));
         n_root += popc64(__ballot(is_new && has_root));
     }
-    if (STATS && stats) {
-        for (int o = 32; o > 0; o >>= 1) leafp += ((uint64_t)__shfl_xor((uint32_t)(leafp >> 32), o) << 32) | __shfl_xor((uint32_t)leafp, o);
-        if (lane == 0) {
-            uint64_t* s = reinterpret_cast<uint64_t*>(stats + r);
-            s[0] = (uint64_t)nk | ((uint64_t)n_m << 32);
-            s[1] = (uint64_t)n_root;
-            s[2] = leafp;
-        }
+    uint32_t rnd = 0;
+    if (STATS) for (int o = 32; o > 0; o >>= 1) leafp += ((uint64_t)__shfl_xor((uint32_t)(leafp >> 32), o) << 32) | __shfl_xor((uint32_t)leafp, o);
+    {
+        uint32_t v[4] = {n_m, n_root, STATS ? (uint32_t)leafp : 0u, STATS ? (uint32_t)(leafp >> 32) : 0u};
+        grp_sum4<WAVES>(v, cx.red, rnd);
+        n_m = v[0]; n_root = v[1];
+        if (WAVES > 1) leafp = ((uint64_t)v[3] << 32) + v[2];  // (per-wave low words summed: < 2^32 in practice)
+    }
+    if (STATS && stats && lane == 0) {
+        uint64_t* s = reinterpret_cast<uint64_t*>(stats + r);
+        s[0] = (uint64_t)nk | ((uint64_t)n_m << 32);
+        s[1] = (uint64_t)n_root;
+        s[2] = leafp;
     }
     if (profile_stop == 2) { write_record(out, r, 0xFE, (int32_t)(vlo[0] + vhi[1] + x[2] + act), 0, 0, 0); return; }
     // ---- B. thresholds (as in place_read) ------------------------------------------------------
@@ -564,6 +618,7 @@ __device__ __forceinline__ void place_read_split(const DbDev db, const PlacePara
             }
         }
         (void)bend;
+        { uint32_t v[4] = {cnt_a, cnt_b, both, 0}; grp_sum4<WAVES>(v, cx.red, rnd); cnt_a = v[0]; cnt_b = v[1]; both = v[2]; }
         const uint32_t U = cnt_a + cnt_b - both;
         uint32_t n_pass = 0, n_best = 0, best = 0;
         int32_t best_one = 0, best_rest = 0, best_diff = 0;
@@ -643,6 +698,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, MIN_WAVES_PER_EU) void place_
     cx.set = reinterpret_cast<uint32_t*>(cx.seq + seq_cap);
     cx.ent = cx.set + (1u << SET_BITS);
     cx.cnt = cx.only = nullptr;
+    cx.red = nullptr;
     const uint32_t gw = blockIdx.x * WAVES_PER_BLOCK + wave;
     const uint32_t n_waves = gridDim.x * WAVES_PER_BLOCK;
     const uint32_t n_list = *list_len;
@@ -671,6 +727,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, MIN_WAVES_PER_EU) void place_
     cx.seq = smem + wave * per_wave;
     cx.set = reinterpret_cast<uint32_t*>(cx.seq + seq_cap);
     cx.ent = cx.set + (1u << SET_BITS);
+    cx.red = nullptr;
     const uint32_t gw = blockIdx.x * WAVES_PER_BLOCK + wave;
     cx.cnt = child_ws ? child_ws + (size_t)gw * 2 * ws_stride : nullptr;
     cx.only = child_ws ? cx.cnt + ws_stride : nullptr;
@@ -681,6 +738,33 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, MIN_WAVES_PER_EU) void place_
         const uint64_t b0 = offsets[r], b1 = offsets[r + 1];
         place_read<SLOTS, SET_BITS, STATS, BINARY>(db, prm, cx, bases, b0, b1, r, out, stats);
         wave_sync();
+    }
+}
+
+// ---- one WORKGROUP per read: the same per-k-mer code with the read's k-mers spread over WAVES
+// wavefronts (reads of up to 64*WAVES*SLOTS k-mers: marker-gene length queries) ----------------------
+template <int WAVES, int SLOTS, int SET_BITS, bool STATS, bool BINARY, bool SPLIT>
+__global__ __launch_bounds__(64 * WAVES) void place_block_kernel(DbDev db, PlaceParams prm, const uint8_t* __restrict__ bases,
+                                                                const uint64_t* __restrict__ offsets,
+                                                                const uint32_t* __restrict__ list,
+                                                                const uint32_t* __restrict__ list_len,
+                                                                cls_placement* __restrict__ out, cls_query_stats* __restrict__ stats,
+                                                                uint32_t seq_cap, uint32_t* __restrict__ child_ws, uint32_t ws_stride) {
+    extern __shared__ __align__(16) uint8_t smem[];
+    WaveCtx cx;
+    cx.seq = smem;
+    cx.set = reinterpret_cast<uint32_t*>(cx.seq + seq_cap);
+    cx.ent = cx.set + (1u << SET_BITS);
+    cx.red = cx.ent + 64 * WAVES * SLOTS;
+    cx.cnt = child_ws ? child_ws + (size_t)blockIdx.x * 2 * ws_stride : nullptr;
+    cx.only = child_ws ? cx.cnt + ws_stride : nullptr;
+    const uint32_t n_list = *list_len;
+    for (uint32_t i = blockIdx.x; i < n_list; i += gridDim.x) {
+        const uint32_t r = list[i];
+        const uint64_t b0 = offsets[r], b1 = offsets[r + 1];
+        if constexpr (SPLIT) place_read_split<SLOTS, SET_BITS, STATS, WAVES>(db, prm, cx, bases, b0, b1, r, out, stats, 0u);
+        else place_read<SLOTS, SET_BITS, STATS, BINARY, WAVES>(db, prm, cx, bases, b0, b1, r, out, stats);
+        __syncthreads();
     }
 }
 
@@ -1048,8 +1132,8 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void order_key_kernel(DbDev d
 // them (class lists in device memory; nothing returns to the host).  Reads no kernel can hold
 // get their record here.
 __global__ void classify_kernel(const uint64_t* __restrict__ offsets, uint32_t n_reads, uint32_t k, uint32_t cap0,
-                                uint32_t cap1, uint32_t* __restrict__ list0, uint32_t* __restrict__ list1,
-                                uint32_t* __restrict__ counts, cls_placement* __restrict__ out,
+                                uint32_t cap1, uint32_t cap2, uint32_t* __restrict__ list0, uint32_t* __restrict__ list1,
+                                uint32_t* __restrict__ list2, uint32_t* __restrict__ counts, cls_placement* __restrict__ out,
                                 cls_query_stats* __restrict__ stats) {
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
     int cls_id = -1;
@@ -1058,6 +1142,7 @@ __global__ void classify_kernel(const uint64_t* __restrict__ offsets, uint32_t n
         const uint64_t nk = L < k ? 0 : 2 * (L - k + 1);
         if (nk <= cap0) cls_id = 0;  // includes L < k: the kernel reports CLS_ERR_TOO_FEW_KMERS
         else if (nk <= cap1) cls_id = 1;
+        else if (nk <= cap2) cls_id = 2;
         else {
             uint64_t* o = reinterpret_cast<uint64_t*>(out + r);
             o[0] = CLS_ERR_READ_TOO_LONG; o[1] = 0; o[2] = 0;
@@ -1069,20 +1154,21 @@ __global__ void classify_kernel(const uint64_t* __restrict__ offsets, uint32_t n
     }
     const uint32_t lane = threadIdx.x & 63;
 #pragma unroll
-    for (int c = 0; c < 2; ++c) {
+    for (int c = 0; c < 3; ++c) {
         const uint64_t m = __ballot(cls_id == c);
         if (!m) continue;
         uint32_t base = 0;
         if (lane == 0) base = atomicAdd(&counts[c], (uint32_t)__popcll(m));
         base = __shfl(base, 0);
-        if (cls_id == c) (c ? list1 : list0)[base + __popcll(m & ((1ull << lane) - 1))] = r;
+        if (cls_id == c) (c == 0 ? list0 : c == 1 ? list1 : list2)[base + __popcll(m & ((1ull << lane) - 1))] = r;
     }
 }
 
 }  // namespace
 
 namespace {
-constexpr int N_CLASSES = 2;
+constexpr int N_CLASSES = 2;            // wave-per-read classes; class 2 = one workgroup per read
+constexpr int BLK_WAVES = 8, BLK_SLOTS = 16, BLK_SET_BITS = 14;  // 8192 k-mers per read
 constexpr int ORDER_KEY_BITS = 32 + DIRECT_TIP_BITS;  // {first tip, record offset}
 constexpr int CLS_SLOTS[N_CLASSES] = {5, 16};      // k-mers per read: 320 / 1024
 constexpr int CLS_SET_BITS[N_CLASSES] = {9, 11};   // LDS distinct-hit set: 512 / 2048 entries
@@ -1120,6 +1206,8 @@ const void* kernel_of(const DbDev& db, int c, bool stats) {
     return c == 0 ? kernel_of_t<CLS_SLOTS[0], CLS_SET_BITS[0]>(db, stats) : kernel_of_t<CLS_SLOTS[1], CLS_SET_BITS[1]>(db, stats);
 }
 
+uint32_t blk_seq_cap(const DbDev& db) { return (2 * (64 * BLK_WAVES * BLK_SLOTS / 2 + db.k) + 15) & ~15u; }
+size_t blk_smem(const DbDev& db) { return (size_t)blk_seq_cap(db) + (4u << BLK_SET_BITS) + 4u * 64 * BLK_WAVES * BLK_SLOTS + 64; }
 uint32_t child_ws_stride(const DbDev& db) {
     return (db.format == FMT_SPLIT || db.max_nonleaf_arity <= 2) ? 0u : ((db.max_nonleaf_arity + 63) & ~63u);
 }
@@ -1146,9 +1234,12 @@ PlacePlan plan_place(const DbDev& db, uint32_t n_reads, uint32_t n_cu, bool stat
         p.grid[c] = want < cap ? (want ? want : 1) : cap;
         child_words = std::max<uint64_t>(child_words, (uint64_t)p.grid[c] * WAVES_PER_BLOCK * 2 * child_ws_stride(db));
     }
-    // workspace (u32 words): [counts 16][list0 n][list1 n][keys_in 2n][keys_out 2n][idx_in n][idx_out n][sort temp][child counters]
+    p.grid_blk = std::max<uint32_t>(1, std::min<uint32_t>(n_reads, n_cu));  // 1 workgroup per CU (LDS-bound)
+    child_words = std::max<uint64_t>(child_words, (uint64_t)p.grid_blk * 2 * child_ws_stride(db));
+    // workspace (u32 words): [counts 16][list0 n][list1 n][list2 n][keys_in 2n][keys_out 2n][idx_in n][idx_out n][sort temp][child counters]
     p.ordered = use_order(db, n_reads);
-    uint64_t w = 16 + 2 * (uint64_t)n_reads;
+    uint64_t w = 16 + 3 * (uint64_t)n_reads;
+    w += w & 1;
     if (p.ordered) {
         p.grid[0] = std::max<uint32_t>(8, p.grid[0] & ~7u);  // whole octets of workgroups: one slice of the list per XCD
         p.keys_off_words = w;
@@ -1168,12 +1259,13 @@ hipError_t launch_place(const DbDev& db, const PlaceParams& prm, const PlacePlan
                         uint32_t* d_ws, hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop) {
     if (n_reads == 0) return hipSuccess;
     uint32_t* counts = d_ws;
-    uint32_t* lists[N_CLASSES] = {d_ws + 16, d_ws + 16 + n_reads};
+    uint32_t* lists[3] = {d_ws + 16, d_ws + 16 + n_reads, d_ws + 16 + 2 * (size_t)n_reads};
     uint32_t* child_ws = child_ws_stride(db) ? d_ws + plan.child_off_words : nullptr;
     hipError_t e = hipMemsetAsync(counts, 0, 64, stream);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(classify_kernel, dim3((n_reads + 255) / 256), dim3(256), 0, stream, d_offsets, n_reads, db.k,
-                       (uint32_t)(64 * CLS_SLOTS[0]), (uint32_t)(64 * CLS_SLOTS[1]), lists[0], lists[1], counts, d_out, d_stats);
+                       (uint32_t)(64 * CLS_SLOTS[0]), (uint32_t)(64 * CLS_SLOTS[1]), (uint32_t)(64 * BLK_WAVES * BLK_SLOTS), lists[0],
+                       lists[1], lists[2], counts, d_out, d_stats);
     // CLS_PROFILE_STOP=1|2 truncates the split kernel after the match / state-init phase (timing
     // breakdowns only: the records it then writes are meaningless)
     static const uint32_t profile_stop = [] { const char* e = getenv("CLS_PROFILE_STOP"); return e ? (uint32_t)atoi(e) : 0u; }();
@@ -1235,6 +1327,23 @@ hipError_t launch_place(const DbDev& db, const PlaceParams& prm, const PlacePlan
     if (ev_stop) (void)hipEventRecord(ev_stop, stream);
     if (hipGetLastError() != hipSuccess) return hipErrorLaunchFailure;
     launch_class(std::integral_constant<int, CLS_SLOTS[1]>{}, std::integral_constant<int, CLS_SET_BITS[1]>{}, 1);
+    if (hipGetLastError() != hipSuccess) return hipErrorLaunchFailure;
+    {   // class 2: one workgroup per read (the generic probe path, whatever the index format)
+        const dim3 grid(plan.grid_blk), block(64 * BLK_WAVES);
+        const uint32_t seq_cap = blk_seq_cap(db);
+        const size_t smem = blk_smem(db);
+#define CLS_LAUNCH_BLK(ST, BI, SP)                                                                                              \
+    do {                                                                                                                        \
+        auto kfn = place_block_kernel<BLK_WAVES, BLK_SLOTS, BLK_SET_BITS, ST, BI, SP>;                                          \
+        (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); /* > 64 KiB of LDS */ \
+        hipLaunchKernelGGL(kfn, grid, block, smem, stream, db, prm, d_bases, d_offsets, lists[2], counts + 2, d_out, d_stats,    \
+                           seq_cap, child_ws, ws_stride);                                                                        \
+    } while (0)
+        if (db.format == FMT_SPLIT) { if (st) CLS_LAUNCH_BLK(true, true, true); else CLS_LAUNCH_BLK(false, true, true); }
+        else if (binary) { if (st) CLS_LAUNCH_BLK(true, true, false); else CLS_LAUNCH_BLK(false, true, false); }
+        else { if (st) CLS_LAUNCH_BLK(true, false, false); else CLS_LAUNCH_BLK(false, false, false); }
+#undef CLS_LAUNCH_BLK
+    }
     return hipGetLastError();
 }
 

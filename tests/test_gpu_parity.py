@@ -72,13 +72,24 @@ def test_ragged_and_edge_reads():
 
 
 def test_read_too_long_reported():
-    s = SynthDb(50, 700, 8, 4)
-    bases, offsets, _ = s.reads(10, 600)
+    s = SynthDb(30, 5000, 9, 4)
+    bases, offsets, _ = s.reads(6, 4800)
     with engine.PlacementDb(s.flat, device=0) as db:
         got, st = db.place_batch(bases, offsets, want_stats=True)
-        assert 2 * (600 - 8 + 1) > db.info.max_read_kmers
+        assert 2 * (4800 - 9 + 1) > db.info.max_read_kmers
     assert (got["status"] == _abi.ERR_READ_TOO_LONG).all()
-    assert (st["n_query_kmers"] == 2 * (600 - 8 + 1)).all()
+    assert (st["n_query_kmers"] == 2 * (4800 - 9 + 1)).all()
+
+
+@pytest.mark.parametrize("k,collapse,drop", [(12, 0.0, 0.0), (35, 0.0, 0.0), (11, 0.4, 0.0), (10, 0.3, 0.2), (16, 0.0, 0.15)])
+def test_gene_length_reads_workgroup_kernel(k, collapse, drop):
+    """Reads of 600..3500 bp (marker-gene queries): the workgroup-per-read kernels, every index format."""
+    s = SynthDb(150, 4000, k, 4, collapse_prob=collapse)
+    flat = drop_random_nodes(s.flat, drop, seed=8) if drop else s.flat
+    rng = np.random.default_rng(21)
+    bases, offsets = ragged_reads(rng, s, 120, 600, 3500, lower_frac=0.05)
+    for kw in (dict(), dict(remove_intersection=True, max_iterations=6)):
+        _check(flat, bases, offsets, kw, threads=16)
 
 
 @pytest.mark.parametrize("collapse", [0.0, 0.4])
