@@ -148,6 +148,7 @@ extern "C" int cls_db_create(const cls_db_desc* d, int device, cls_db** out) {
         v.m_eff = E.m_eff;
         v.max_nonleaf_arity = E.max_nonleaf_arity;
         v.format = E.format;
+        v.addr32 = (E.postings.size() * 4 < (1ull << 32) && E.direct.size() * 4 < (1ull << 32)) ? 1u : 0u;
         cls_db_info& i = db->info;
         i.n_nodes = v.n_nodes;
         i.max_depth = E.max_depth;

@@ -105,6 +105,8 @@ struct DbDev {
     uint32_t m_eff;      // min(mSize, kSize): chars().take(m), kmers_map.rs:11
     uint32_t max_nonleaf_arity;
     uint32_t format;     // FMT_*; Slot.loc offsets are in words (LIST) or records (SPLIT)
+    uint32_t addr32;     // postings and direct table are both below 4 GiB: 32-bit byte offsets suffice
+    uint32_t pad_;
 };
 
 // Resolved Option<> arguments (place_sequence.rs:64-75)

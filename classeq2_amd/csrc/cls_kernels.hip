@@ -796,6 +796,15 @@ __device__ __forceinline__ snode_t load_node(const DNode* nodes, uint32_t row) {
     return r;
 }
 
+// Indexed load off a wave-uniform base.  ADDR32: the byte offset is known to fit 32 bits (arrays below
+// 4 GiB), which lets the compiler use the SGPR-base + 32-bit-VGPR-offset form instead of building a 64-bit
+// address pair per access (each pair costs an extra VGPR holding the zero high half).
+template <class T, bool ADDR32>
+__device__ __forceinline__ T ldx(const void* base, uint32_t index) {
+    if constexpr (ADDR32) return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + (uint32_t)(index * (uint32_t)sizeof(T)));
+    else return reinterpret_cast<const T*>(base)[index];
+}
+
 struct FastCtx {
     uint8_t* ascii;    // LDS: upper-cased read, L bytes
     uint32_t* packed;  // LDS: the read 2 bits per base, base i at bits 2(i & 15) of word i >> 4
@@ -805,7 +814,7 @@ struct FastCtx {
 // Front of the fast path, shared with order_key_kernel: the read -> LDS (upper-cased, validated),
 // 2 bits per base, then per query k-mer its 2-bit code and the direct-table entry.
 // Returns false if the read holds a character other than ACGT.
-template <int SLOTS, int SET_BITS>
+template <int SLOTS, int SET_BITS, bool ADDR32>
 __device__ __forceinline__ bool fast_front(const DbDev& db, const FastCtx& cx, const uint8_t* __restrict__ bases, uint64_t b0,
                                            uint32_t L, uint32_t nf, uint32_t nk, uint32_t (&off)[SLOTS], uint32_t (&meta)[SLOTS]) {
     const uint32_t lane = threadIdx.x & 63;
@@ -838,7 +847,7 @@ __device__ __forceinline__ bool fast_front(const DbDev& db, const FastCtx& cx, c
         }
     }
     wave_sync();
-    const uint2* __restrict__ direct = reinterpret_cast<const uint2*>(db.direct);
+    const uint32_t* __restrict__ direct = db.direct;
     const uint32_t kmask = (k == 16) ? 0xFFFFFFFFu : ((1u << (2 * k)) - 1u);
 #pragma unroll
     for (int s = 0; s < SLOTS; ++s) {
@@ -854,14 +863,14 @@ __device__ __forceinline__ bool fast_front(const DbDev& db, const FastCtx& cx, c
         rcc = ((rcc >> 1) & 0x55555555u) | ((rcc & 0x55555555u) << 1);
         rcc >>= (32 - 2 * k);
         code = rc ? rcc : code;
-        const uint2 e = direct[valid ? code : 0u];
+        const uint2 e = ldx<uint2, ADDR32>(direct, valid ? code : 0u);
         off[s] = valid ? e.x : 0u;
         meta[s] = valid ? e.y : 0xFFFFFFFFu;
     }
     return true;
 }
 
-template <int SLOTS, int SET_BITS, bool STATS>
+template <int SLOTS, int SET_BITS, bool STATS, bool ADDR32>
 __device__ __forceinline__ void place_read_fast(const DbDev& db, const PlaceParams& prm, const FastCtx& cx,
                                                 const uint8_t* __restrict__ bases, uint64_t b0, uint64_t b1, uint32_t r,
                                                 cls_placement* __restrict__ out, cls_query_stats* __restrict__ stats,
@@ -881,12 +890,12 @@ __device__ __forceinline__ void place_read_fast(const DbDev& db, const PlacePara
     const uint32_t L = (uint32_t)L64, nf = L - k + 1, nk = 2 * nf;  // nk <= 64*SLOTS by classification
     // ---- A1/A2. load + validate + 2-bit pack; per k-mer: code -> direct table ----------------------
     uint32_t off[SLOTS], meta[SLOTS];
-    if (!fast_front<SLOTS, SET_BITS>(db, cx, bases, b0, L, nf, nk, off, meta)) {
+    if (!fast_front<SLOTS, SET_BITS, ADDR32>(db, cx, bases, b0, L, nf, nk, off, meta)) {
         put_stats(0, 0, 0, 0);
         write_record(out, r, CLS_ERR_INVALID_BASE, 0, 0, 0, 0);
         return;
     }
-    const uint4* __restrict__ recs = reinterpret_cast<const uint4*>(db.postings);
+    const uint32_t* __restrict__ recs = db.postings;
     // distinct hashes: the FIRST k-mer that reaches an entry keeps it (HashSet<u64> semantics)
 #pragma unroll
     for (int s = 0; s < SLOTS; ++s) {
@@ -909,8 +918,8 @@ __device__ __forceinline__ void place_read_fast(const DbDev& db, const PlacePara
     uint64_t leafp = 0;
 #pragma unroll
     for (int s = 0; s < SLOTS; ++s) {
-        const uint4 hd = recs[off[s]];  // {n | flags, root split, first tip, last tip}
-        if (STATS) leafp += recs[off[s] + 1].x;
+        const uint4 hd = ldx<uint4, ADDR32>(recs, off[s]);  // {n | flags, root split, first tip, last tip}
+        if (STATS) leafp += ldx<uint4, ADDR32>(recs, off[s] + 1).x;
         vlo[s] = hd.z;
         vhi[s] = hd.w;
         x[s] = hd.y;
@@ -935,7 +944,7 @@ __device__ __forceinline__ void place_read_fast(const DbDev& db, const PlacePara
         if ((uint64_t)n_root < exp_usize) { write_record(out, r, CLS_UNCLASSIFIABLE_COVERAGE, (int32_t)n_root, 0, 0, 0); return; }
     }
     // ---- C. descent -----------------------------------------------------------------------------------
-    const uint2* __restrict__ half = reinterpret_cast<const uint2*>(db.postings);  // record x = halves 2x (left), 2x+1 (right)
+    const uint32_t* __restrict__ half = db.postings;  // record x = 8-byte halves 2x (left part), 2x+1 (right part)
     const bool rm = prm.remove_intersection != 0;
     int32_t iteration = 0;
     for (;;) {
@@ -988,7 +997,7 @@ __device__ __forceinline__ void place_read_fast(const DbDev& db, const PlacePara
 #pragma unroll
             for (int s = 0; s < SLOTS; ++s) {
                 const bool str = vlo[s] < a1 && vlo[s] != a0 && vhi[s] >= a1;
-                t[s] = profile_stop == 3 ? uint2{vhi[s] >> 1, x[s]} : half[str ? 2 * (size_t)x[s] : 0];
+                t[s] = profile_stop == 3 ? uint2{vhi[s] >> 1, x[s]} : ldx<uint2, ADDR32>(half, str ? 2 * x[s] : 0u);
             }
 #pragma unroll
             for (int s = 0; s < SLOTS; ++s) {
@@ -1002,7 +1011,7 @@ __device__ __forceinline__ void place_read_fast(const DbDev& db, const PlacePara
 #pragma unroll
             for (int s = 0; s < SLOTS; ++s) {
                 const bool str = vhi[s] >= a1 && vlo[s] < a1;
-                t[s] = profile_stop == 3 ? uint2{vlo[s] + 1, x[s]} : half[str ? 2 * (size_t)x[s] + 1 : 0];
+                t[s] = profile_stop == 3 ? uint2{vlo[s] + 1, x[s]} : ldx<uint2, ADDR32>(half, str ? 2 * x[s] + 1 : 0u);
             }
 #pragma unroll
             for (int s = 0; s < SLOTS; ++s) {
@@ -1015,7 +1024,7 @@ __device__ __forceinline__ void place_read_fast(const DbDev& db, const PlacePara
     }
 }
 
-template <int SLOTS, int SET_BITS, bool STATS>
+template <int SLOTS, int SET_BITS, bool STATS, bool ADDR32>
 __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, MIN_WAVES_PER_EU) void place_fast_kernel(
     DbDev db, PlaceParams prm, const uint8_t* __restrict__ bases, const uint64_t* __restrict__ offsets,
     const uint32_t* __restrict__ list, const uint32_t* __restrict__ list_len, uint32_t list_n, uint32_t xcd_chunks,
@@ -1042,7 +1051,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, MIN_WAVES_PER_EU) void place_
             const uint64_t b0 = offsets[r], b1 = offsets[r + 1];
             const uint64_t L64 = b1 - b0;
             if (L64 >= db.k && 2 * (L64 - db.k + 1) > cap) continue;  // another class' read (classify_kernel binned it)
-            place_read_fast<SLOTS, SET_BITS, STATS>(db, prm, cx, bases, b0, b1, r, out, stats, profile_stop);
+            place_read_fast<SLOTS, SET_BITS, STATS, ADDR32>(db, prm, cx, bases, b0, b1, r, out, stats, profile_stop);
             wave_sync();
         }
         return;
@@ -1053,7 +1062,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, MIN_WAVES_PER_EU) void place_
     for (uint32_t i = gw; i < n_list; i += n_waves) {
         const uint32_t r = list[i];
         const uint64_t b0 = offsets[r], b1 = offsets[r + 1];
-        place_read_fast<SLOTS, SET_BITS, STATS>(db, prm, cx, bases, b0, b1, r, out, stats, profile_stop);
+        place_read_fast<SLOTS, SET_BITS, STATS, ADDR32>(db, prm, cx, bases, b0, b1, r, out, stats, profile_stop);
         wave_sync();
     }
 }
@@ -1062,7 +1071,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, MIN_WAVES_PER_EU) void place_
 // most specific one (fewest tips; ties: smaller first tip, then smaller record offset) names a leaf
 // neighbourhood (its first tip) and, through its record offset, a group of overlapping reads.
 // Reads the fast kernel will not place (too short / too long / bad characters) get the last key.
-template <int SLOTS>
+template <int SLOTS, bool ADDR32>
 __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void order_key_kernel(DbDev db, const uint8_t* __restrict__ bases,
                                                                        const uint64_t* __restrict__ offsets, uint32_t n_reads,
                                                                        uint64_t* __restrict__ keys, uint32_t* __restrict__ idx,
@@ -1084,7 +1093,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void order_key_kernel(DbDev d
         if (L64 >= db.k && 2 * (L64 - db.k + 1) <= (uint64_t)(64 * SLOTS)) {
             const uint32_t L = (uint32_t)L64, nf = L - db.k + 1, nk = 2 * nf;
             uint32_t off[SLOTS], meta[SLOTS];
-            if (fast_front<SLOTS, 0>(db, cx, bases, b0, L, nf, nk, off, meta)) {
+            if (fast_front<SLOTS, 0, ADDR32>(db, cx, bases, b0, L, nf, nk, off, meta)) {
                 // candidates: k-mers present in the index that are specific to a small clade (few tips);
                 // the tip bound is widened until a handful qualify (finally: every k-mer present)
                 uint32_t cand = 0, n_cand = 0;
@@ -1194,8 +1203,10 @@ size_t smem_of(const DbDev& db, int c) {
 
 template <int SLOTS, int SET_BITS>
 const void* kernel_of_t(const DbDev& db, bool stats) {
-    if (use_fast(db))
-        return stats ? (const void*)place_fast_kernel<SLOTS, SET_BITS, true> : (const void*)place_fast_kernel<SLOTS, SET_BITS, false>;
+    if (use_fast(db)) {
+        if (db.addr32) return stats ? (const void*)place_fast_kernel<SLOTS, SET_BITS, true, true> : (const void*)place_fast_kernel<SLOTS, SET_BITS, false, true>;
+        return stats ? (const void*)place_fast_kernel<SLOTS, SET_BITS, true, false> : (const void*)place_fast_kernel<SLOTS, SET_BITS, false, false>;
+    }
     if (db.format == FMT_SPLIT)
         return stats ? (const void*)place_split_kernel<SLOTS, SET_BITS, true> : (const void*)place_split_kernel<SLOTS, SET_BITS, false>;
     const bool binary = db.max_nonleaf_arity <= 2;  // no node has more than two non-LEAF children
@@ -1241,6 +1252,9 @@ PlacePlan plan_place(const DbDev& db, uint32_t n_reads, uint32_t n_cu, bool stat
     uint64_t w = 16 + 3 * (uint64_t)n_reads;
     w += w & 1;
     if (p.ordered) {
+        // 3 workgroups (12 reads) per CU measured best: more reads in flight per XCD evict each other's
+        // lines from its 4 MiB L2 faster than the extra latency hiding pays (2: 16.9 ms, 3: 15.9, 4: 19.0 on C3)
+        if (forced <= 0) p.grid[0] = std::min<uint32_t>(p.grid[0], 3 * n_cu);
         p.grid[0] = std::max<uint32_t>(8, p.grid[0] & ~7u);  // whole octets of workgroups: one slice of the list per XCD
         p.keys_off_words = w;
         w += 6 * (uint64_t)n_reads;
@@ -1285,8 +1299,12 @@ hipError_t launch_place(const DbDev& db, const PlaceParams& prm, const PlacePlan
         static const uint32_t spec_lg = [] { const char* v = getenv("CLS_ORDER_SPEC_LG"); return v ? (uint32_t)atoi(v) : 3u; }();
         static const uint32_t block_shift = [] { const char* v = getenv("CLS_ORDER_BLOCK_SHIFT"); return v ? (uint32_t)atoi(v) : 2u; }();
         const size_t smem_k = (size_t)WAVES_PER_BLOCK * (ac + 4u * ((ac >> 4) + 2) + 16u);
-        hipLaunchKernelGGL((order_key_kernel<CLS_SLOTS[0]>), dim3(plan.grid[0]), dim3(64 * WAVES_PER_BLOCK), smem_k, stream, db, d_bases,
-                           d_offsets, n_reads, keys_in, idx_in, ac, tip_bits, spec_lg, block_shift);
+        if (db.addr32)
+            hipLaunchKernelGGL((order_key_kernel<CLS_SLOTS[0], true>), dim3(plan.grid[0]), dim3(64 * WAVES_PER_BLOCK), smem_k, stream, db,
+                               d_bases, d_offsets, n_reads, keys_in, idx_in, ac, tip_bits, spec_lg, block_shift);
+        else
+            hipLaunchKernelGGL((order_key_kernel<CLS_SLOTS[0], false>), dim3(plan.grid[0]), dim3(64 * WAVES_PER_BLOCK), smem_k, stream, db,
+                               d_bases, d_offsets, n_reads, keys_in, idx_in, ac, tip_bits, spec_lg, block_shift);
         e = sort_pairs(d_ws + plan.sort_off_words, plan.sort_bytes, keys_in, keys_out, idx_in, idx_out, n_reads, ORDER_KEY_BITS, stream);
         if (e != hipSuccess) return e;
         list0 = idx_out;
@@ -1302,10 +1320,12 @@ hipError_t launch_place(const DbDev& db, const PlaceParams& prm, const PlacePlan
             const uint32_t ac = ascii_cap_of(db, c);
             const uint32_t* lst = c == 0 ? list0 : lists[c];
             const uint32_t ln = c == 0 ? list0_n : 0u, xc = c == 0 ? xcd_chunks : 0u;
-            if (st) hipLaunchKernelGGL((place_fast_kernel<SLOTS, SET_BITS, true>), grid, block, smem, stream, db, prm, d_bases, d_offsets,
-                                       lst, counts + c, ln, xc, d_out, d_stats, ac, profile_stop);
-            else hipLaunchKernelGGL((place_fast_kernel<SLOTS, SET_BITS, false>), grid, block, smem, stream, db, prm, d_bases, d_offsets,
-                                    lst, counts + c, ln, xc, d_out, d_stats, ac, profile_stop);
+#define CLS_LAUNCH_FAST(ST, A32)                                                                                              \
+    hipLaunchKernelGGL((place_fast_kernel<SLOTS, SET_BITS, ST, A32>), grid, block, smem, stream, db, prm, d_bases, d_offsets, \
+                       lst, counts + c, ln, xc, d_out, d_stats, ac, profile_stop)
+            if (db.addr32) { if (st) CLS_LAUNCH_FAST(true, true); else CLS_LAUNCH_FAST(false, true); }
+            else { if (st) CLS_LAUNCH_FAST(true, false); else CLS_LAUNCH_FAST(false, false); }
+#undef CLS_LAUNCH_FAST
             return;
         }
         if (db.format == FMT_SPLIT) {
