@@ -117,6 +117,10 @@ class DbInfo(C.Structure):
         ("hbm_bytes", C.c_uint64),
         ("max_read_kmers", C.c_uint32),
         ("device", C.c_int32),
+        ("format", C.c_uint32),
+        ("binary_tree", C.c_uint32),
+        ("direct_table", C.c_uint32),
+        ("pad_", C.c_uint32),
     ]
 
 

@@ -148,6 +148,7 @@ extern "C" int cls_db_create(const cls_db_desc* d, int device, cls_db** out) {
         v.m_eff = E.m_eff;
         v.max_nonleaf_arity = E.max_nonleaf_arity;
         v.format = E.format;
+        v.binary_tree = E.strictly_binary ? 1u : 0u;
         v.addr32 = (E.postings.size() * 4 < (1ull << 32) && E.direct.size() * 4 < (1ull << 32)) ? 1u : 0u;
         cls_db_info& i = db->info;
         i.n_nodes = v.n_nodes;
@@ -163,6 +164,9 @@ extern "C" int cls_db_create(const cls_db_desc* d, int device, cls_db** out) {
         i.hbm_bytes = E.nodes.size() * sizeof(cls::DNode) + E.table.size() * sizeof(cls::Slot) + E.postings.size() * 4 + E.bucket_key.size() * 8 + E.direct.size() * 4;
         i.max_read_kmers = cls::MAX_READ_KMERS;
         i.device = device;
+        i.format = E.format;
+        i.binary_tree = E.strictly_binary ? 1u : 0u;
+        i.direct_table = E.direct.empty() ? 0u : 1u;
         *out = db;
         return CLS_OK;
     } catch (const std::bad_alloc&) {

@@ -5,6 +5,8 @@
 
 #include "cls_murmur.h"
 
+#include <stdlib.h>
+
 #include <algorithm>
 #include <atomic>
 #include <functional>
@@ -203,7 +205,8 @@ int encode_db(const cls_db_desc* d, EncodedDb& E, std::string& err) {
     E.strictly_binary = true;
     for (uint32_t r = 0; r < N; ++r)
         if (d->nodes[order[r]].n_children != 0 && d->nodes[order[r]].n_children != 2) { E.strictly_binary = false; break; }
-    E.format = (E.strictly_binary && n_closed.load() == NK) ? FMT_SPLIT : FMT_LIST;
+    // CLS_FORCE_LIST=1 keeps the sorted-list form (A/B experiments only)
+    E.format = (n_closed.load() == NK && getenv("CLS_FORCE_LIST") == nullptr) ? FMT_SPLIT : FMT_LIST;
     if (E.format == FMT_SPLIT) {
         // per k-mer: 2 header records + (n-1) split nodes + (n == 1 ? 0 : 0) ... see cls_device.h
         std::vector<uint64_t> rec_off(NK + 1, 0);
@@ -301,7 +304,7 @@ int encode_db(const cls_db_desc* d, EncodedDb& E, std::string& err) {
         E.table[i] = Slot{h, (off << LOC_BUCKET_BITS) | bucket_of[j]};
     }
     // ---- 6. direct table for small k -----------------------------------------------------
-    if (E.format == FMT_SPLIT && d->k_size <= DIRECT_MAX_K) {
+    if (E.format == FMT_SPLIT && E.strictly_binary && d->k_size <= DIRECT_MAX_K) {
         const uint32_t K = (uint32_t)d->k_size, M = (uint32_t)std::min<uint64_t>(d->m_size, d->k_size);
         const uint64_t n_codes = 1ULL << (2 * K);
         E.direct.assign(2 * n_codes, 0);  // {record offset, locality meta} per code

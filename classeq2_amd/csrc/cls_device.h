@@ -52,8 +52,7 @@ constexpr uint32_t POST_LEN_MASK = (1u << 30) - 1;
 constexpr uint32_t POST_HEADER_WORDS = 2;
 
 // ---- postings, "split-tree" form (FMT_SPLIT) ----------------------------------
-// Used when EVERY node set is closed under `parent` AND every clade has exactly
-// zero or two children.  16-byte records; a k-mer with n tips owns 2 header
+// Used when EVERY node set is closed under `parent` (every `cls build-db` output).  16-byte records; a k-mer with n tips owns 2 header
 // records + (n-1) split nodes:
 //   header 0 : {n | POST_HAS_ROOT | POST_CLOSED, root split (record index, 0 = none), first tip, last tip}
 //   header 1 : {n_leaf_ids (statistics), hash lo, hash hi, minimizer-bucket index}
@@ -106,7 +105,7 @@ struct DbDev {
     uint32_t max_nonleaf_arity;
     uint32_t format;     // FMT_*; Slot.loc offsets are in words (LIST) or records (SPLIT)
     uint32_t addr32;     // postings and direct table are both below 4 GiB: 32-bit byte offsets suffice
-    uint32_t pad_;
+    uint32_t binary_tree; // every clade has exactly zero or two children
 };
 
 // Resolved Option<> arguments (place_sequence.rs:64-75)

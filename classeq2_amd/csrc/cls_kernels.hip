@@ -159,6 +159,7 @@ struct WaveCtx {
     uint32_t* ent;   // LDS: per k-mer, postings offset of its (first-seen) hit or SET_EMPTY
     uint32_t* cnt;   // general path: |K_c| per non-LEAF child
     uint32_t* only;  // general path: |K_c \ R_c| per non-LEAF child
+    bool child_global;  // cnt/only live in global scratch (huge polytomies) rather than LDS: needs agent-scope fences
     uint32_t* red;   // LDS: 3 x 4 words for the cross-wave sums of a multi-wave group (unused when one wave places a read)
 };
 
@@ -434,7 +435,7 @@ __device__ __forceinline__ void place_read(const DbDev db, const PlaceParams prm
                 __hip_atomic_store(&cx.only[i], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (WAVES > 1) __hip_atomic_store(&cx.cnt[i], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
-            if (WAVES > 1) { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent"); __syncthreads(); }
+            if (WAVES > 1) { if (cx.child_global) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent"); __syncthreads(); }
             uint32_t nin[SLOTS], which[SLOTS];
 #pragma unroll
             for (int s = 0; s < SLOTS; ++s) { nin[s] = 0; which[s] = 0; }
@@ -461,7 +462,7 @@ __device__ __forceinline__ void place_read(const DbDev db, const PlaceParams prm
                 if (nin[s] == 1) __hip_atomic_fetch_add(&cx.only[which[s]], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             { uint32_t v[4] = {U, 0, 0, 0}; grp_sum4<WAVES>(v, cx.red, rnd); U = v[0]; }
-            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+            if (cx.child_global) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
             grp_sync<WAVES>();
             for (uint32_t base = 0; base < m; base += 64) {
                 const uint32_t ci = base + lane;
@@ -537,7 +538,7 @@ __device__ __forceinline__ void place_read(const DbDev db, const PlaceParams prm
 // ---- FMT_SPLIT: every node set closed, every clade has 0 or 2 children ---------------------
 // Per k-mer only (vlo, vhi, x) live in registers: the smallest / largest tip inside the current
 // clade and the record index of the split that parts them at their LCA (cls_device.h).
-template <int SLOTS, int SET_BITS, bool STATS, int WAVES = 1>
+template <int SLOTS, int SET_BITS, bool STATS, int WAVES = 1, bool POLY = false>
 __device__ __forceinline__ void place_read_split(const DbDev db, const PlaceParams prm, const WaveCtx cx,
                                                  const uint8_t* __restrict__ bases, uint64_t b0, uint64_t b1, uint32_t r,
                                                  cls_placement* __restrict__ out, cls_query_stats* __restrict__ stats,
@@ -601,7 +602,128 @@ __device__ __forceinline__ void place_read_split(const DbDev db, const PlacePara
         ++iteration;
         if (iteration > prm.max_iterations) { write_record(out, r, CLS_ERR_MAX_ITER, 0, 0, (uint32_t)iteration, 0); return; }
         const uint32_t fc = uniform(nodes[prow].first_child);
-        const uint32_t m = uniform(nodes[prow].n_nonleaf);  // 0, 1 or 2; the non-LEAF children come first
+        const uint32_t m = uniform(nodes[prow].n_nonleaf);  // the non-LEAF children come first
+        if (POLY && (uniform(nodes[prow].flags) >> 8) != 2) {
+            // ---- a clade that does not have exactly two children (polytomy after support collapse) -------
+            // The Cartesian tree breaks ties to the left, so the splits between a k-mer's occupied children
+            // form a right-going chain: walk the non-LEAF children left to right, stepping a k-mer past a
+            // child's end with one record read when it has tips on both sides of it.
+            uint32_t s_vlo[SLOTS], s_vhi[SLOTS], s_x[SLOTS], nin[SLOTS], which[SLOTS];
+#pragma unroll
+            for (int s = 0; s < SLOTS; ++s) { s_vlo[s] = vlo[s]; s_vhi[s] = vhi[s]; s_x[s] = x[s]; nin[s] = 0; which[s] = 0; }
+            const uint32_t s_act = act;
+            auto step_right = [&](uint32_t c_end, uint32_t& live) {  // restrict every live k-mer to its tips >= c_end
+                constexpr int G = SLOTS <= 5 ? SLOTS : 4;
+#pragma unroll
+                for (int g0 = 0; g0 < SLOTS; g0 += G) {
+                    uint4 t[G];
+#pragma unroll
+                    for (int i = 0; i < G; ++i) {
+                        const int s = g0 + i;
+                        const bool str = s < SLOTS && ((live >> s) & 1u) && vlo[s] < c_end && vhi[s] >= c_end;
+                        t[i] = recs[str ? x[s] : 0u];
+                    }
+#pragma unroll
+                    for (int i = 0; i < G; ++i) {
+                        const int s = g0 + i;
+                        if (s >= SLOTS || !((live >> s) & 1u)) continue;
+                        if (vhi[s] < c_end) live &= ~(1u << s);                        // nothing at or beyond c_end
+                        else if (vlo[s] < c_end) { vlo[s] = t[i].z; x[s] = t[i].w; }   // first tip >= c_end, split of the rest
+                    }
+                }
+            };
+            for (uint32_t i = tid; i < m; i += GS) {
+                __hip_atomic_store(&cx.only[i], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (WAVES > 1) __hip_atomic_store(&cx.cnt[i], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (WAVES > 1) { if (cx.child_global) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent"); __syncthreads(); }
+            uint32_t live = act;
+            for (uint32_t ci = 0; ci < m; ++ci) {
+                const uint32_t c_end = uniform(nodes[fc + ci].pre) + uniform(nodes[fc + ci].size);
+                uint32_t cn = 0;
+#pragma unroll
+                for (int s = 0; s < SLOTS; ++s) {
+                    const bool in = ((live >> s) & 1u) && vlo[s] < c_end;  // vlo >= start of child ci for a live k-mer
+                    if (in) { if (nin[s] == 0) which[s] = ci; if (nin[s] < 2) ++nin[s]; }
+                    cn += popc64(__ballot(in));
+                }
+                if (lane == 0) {
+                    if (WAVES == 1) __hip_atomic_store(&cx.cnt[ci], cn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    else if (cn) __hip_atomic_fetch_add(&cx.cnt[ci], cn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                step_right(c_end, live);
+            }
+            uint32_t U = 0;
+#pragma unroll
+            for (int s = 0; s < SLOTS; ++s) {
+                U += popc64(__ballot(nin[s] >= 1));
+                if (nin[s] == 1) __hip_atomic_fetch_add(&cx.only[which[s]], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            { uint32_t v[4] = {U, 0, 0, 0}; grp_sum4<WAVES>(v, cx.red, rnd); U = v[0]; }
+            if (cx.child_global) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+            grp_sync<WAVES>();
+            uint32_t n_pass = 0, n_best = 0, best_row = 0;
+            int32_t best_one = 0, best_rest = 0, best_diff = 0;
+            for (uint32_t base = 0; base < m; base += 64) {
+                const uint32_t ci = base + lane;
+                bool pass = false;
+                int32_t one = 0, rest = 0;
+                if (ci < m) {
+                    const uint32_t cn = __hip_atomic_load(&cx.cnt[ci], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const uint32_t on = __hip_atomic_load(&cx.only[ci], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (cn) { one = (int32_t)(rm ? on : cn); rest = (int32_t)(rm ? U - cn : U - on); pass = one > rest; }
+                }
+                uint64_t pm = __ballot(pass);
+                while (pm) {
+                    const int src = __ffsll((unsigned long long)pm) - 1;
+                    const int32_t o1 = __shfl(one, src), r1 = __shfl(rest, src);
+                    const int32_t diff = o1 - r1;
+                    if (n_pass == 0 || diff > best_diff) { best_diff = diff; n_best = 1; best_row = fc + base + src; best_one = o1; best_rest = r1; }
+                    else if (diff == best_diff) ++n_best;
+                    ++n_pass;
+                    pm &= pm - 1;
+                }
+            }
+            grp_sync<WAVES>();
+            if (n_pass == 0) {
+                if (iteration == 1) write_record(out, r, CLS_UNCLASSIFIABLE_LEVEL1, 0, 0, 1, 0);
+                else write_record(out, r, CLS_MAX_RESOLUTION, 0, 0, (uint32_t)iteration, nodes[prow].id);
+                return;
+            }
+            if (n_pass > 1 && n_best != 1) { write_record(out, r, CLS_INCONCLUSIVE, (int32_t)n_pass, 0, (uint32_t)iteration, nodes[prow].id); return; }
+            if (uniform(nodes[best_row].n_nonleaf) == 0) {
+                write_record(out, r, CLS_IDENTITY_FOUND, best_one, best_rest, (uint32_t)iteration, nodes[best_row].id);
+                return;
+            }
+            // back to the state at the top of this level, step past the children before the chosen one, enter it
+#pragma unroll
+            for (int s = 0; s < SLOTS; ++s) { vlo[s] = s_vlo[s]; vhi[s] = s_vhi[s]; x[s] = s_x[s]; }
+            act = s_act;
+            for (uint32_t row = fc; row < best_row; ++row) step_right(uniform(nodes[row].pre) + uniform(nodes[row].size), act);
+            {
+                const uint32_t c0 = uniform(nodes[best_row].pre), c_end = c0 + uniform(nodes[best_row].size);
+                constexpr int G = SLOTS <= 5 ? SLOTS : 4;
+#pragma unroll
+                for (int g0 = 0; g0 < SLOTS; g0 += G) {
+                    uint4 t[G];
+#pragma unroll
+                    for (int i = 0; i < G; ++i) {
+                        const int s = g0 + i;
+                        const bool str = s < SLOTS && ((act >> s) & 1u) && vlo[s] < c_end && vlo[s] != c0 && vhi[s] >= c_end;
+                        t[i] = recs[str ? x[s] : 0u];
+                    }
+#pragma unroll
+                    for (int i = 0; i < G; ++i) {
+                        const int s = g0 + i;
+                        if (s >= SLOTS || !((act >> s) & 1u)) continue;
+                        if (vlo[s] >= c_end || vlo[s] == c0) act &= ~(1u << s);            // not below the chosen clade
+                        else if (vhi[s] >= c_end) { vhi[s] = t[i].x; x[s] = t[i].y; }     // keep the part inside it
+                    }
+                }
+            }
+            prow = best_row;
+            continue;
+        }
         uint32_t a0 = 0, a1 = 0, bend = 0;
         if (m >= 1) { a0 = uniform(nodes[fc].pre); a1 = a0 + uniform(nodes[fc].size); }
         // the second child starts at a1 whatever its kind; it is scored only if it is not a LEAF
@@ -685,11 +807,12 @@ __device__ __forceinline__ void place_read_split(const DbDev db, const PlacePara
     }
 }
 
-template <int SLOTS, int SET_BITS, bool STATS>
+template <int SLOTS, int SET_BITS, bool STATS, bool POLY>
 __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, MIN_WAVES_PER_EU) void place_split_kernel(
     DbDev db, PlaceParams prm, const uint8_t* __restrict__ bases, const uint64_t* __restrict__ offsets,
     const uint32_t* __restrict__ list, const uint32_t* __restrict__ list_len,
-    cls_placement* __restrict__ out, cls_query_stats* __restrict__ stats, uint32_t seq_cap, uint32_t profile_stop) {
+    cls_placement* __restrict__ out, cls_query_stats* __restrict__ stats, uint32_t seq_cap, uint32_t profile_stop,
+    uint32_t* __restrict__ child_ws, uint32_t ws_stride) {
     extern __shared__ __align__(16) uint8_t smem[];
     const uint32_t wave = threadIdx.x >> 6;
     const uint32_t per_wave = seq_cap + (4u << SET_BITS) + 4u * 64 * SLOTS;
@@ -697,15 +820,18 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, MIN_WAVES_PER_EU) void place_
     cx.seq = smem + wave * per_wave;
     cx.set = reinterpret_cast<uint32_t*>(cx.seq + seq_cap);
     cx.ent = cx.set + (1u << SET_BITS);
-    cx.cnt = cx.only = nullptr;
     cx.red = nullptr;
     const uint32_t gw = blockIdx.x * WAVES_PER_BLOCK + wave;
+    cx.child_global = child_ws != nullptr;
+    cx.cnt = child_ws ? child_ws + (size_t)gw * 2 * ws_stride
+                      : reinterpret_cast<uint32_t*>(smem + WAVES_PER_BLOCK * per_wave) + (size_t)wave * 2 * ws_stride;  // LDS (ws_stride may be 0)
+    cx.only = cx.cnt + ws_stride;
     const uint32_t n_waves = gridDim.x * WAVES_PER_BLOCK;
     const uint32_t n_list = *list_len;
     for (uint32_t i = gw; i < n_list; i += n_waves) {
         const uint32_t r = list[i];
         const uint64_t b0 = offsets[r], b1 = offsets[r + 1];
-        place_read_split<SLOTS, SET_BITS, STATS>(db, prm, cx, bases, b0, b1, r, out, stats, profile_stop);
+        place_read_split<SLOTS, SET_BITS, STATS, 1, POLY>(db, prm, cx, bases, b0, b1, r, out, stats, profile_stop);
         wave_sync();
     }
 }
@@ -729,8 +855,10 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, MIN_WAVES_PER_EU) void place_
     cx.ent = cx.set + (1u << SET_BITS);
     cx.red = nullptr;
     const uint32_t gw = blockIdx.x * WAVES_PER_BLOCK + wave;
-    cx.cnt = child_ws ? child_ws + (size_t)gw * 2 * ws_stride : nullptr;
-    cx.only = child_ws ? cx.cnt + ws_stride : nullptr;
+    cx.child_global = child_ws != nullptr;
+    cx.cnt = child_ws ? child_ws + (size_t)gw * 2 * ws_stride
+                      : reinterpret_cast<uint32_t*>(smem + WAVES_PER_BLOCK * per_wave) + (size_t)wave * 2 * ws_stride;  // LDS (ws_stride may be 0)
+    cx.only = cx.cnt + ws_stride;
     const uint32_t n_waves = gridDim.x * WAVES_PER_BLOCK;
     const uint32_t n_list = *list_len;
     for (uint32_t i = gw; i < n_list; i += n_waves) {
@@ -756,13 +884,14 @@ __global__ __launch_bounds__(64 * WAVES) void place_block_kernel(DbDev db, Place
     cx.set = reinterpret_cast<uint32_t*>(cx.seq + seq_cap);
     cx.ent = cx.set + (1u << SET_BITS);
     cx.red = cx.ent + 64 * WAVES * SLOTS;
-    cx.cnt = child_ws ? child_ws + (size_t)blockIdx.x * 2 * ws_stride : nullptr;
-    cx.only = child_ws ? cx.cnt + ws_stride : nullptr;
+    cx.child_global = child_ws != nullptr;
+    cx.cnt = child_ws ? child_ws + (size_t)blockIdx.x * 2 * ws_stride : cx.red + 16;  // LDS (ws_stride may be 0)
+    cx.only = cx.cnt + ws_stride;
     const uint32_t n_list = *list_len;
     for (uint32_t i = blockIdx.x; i < n_list; i += gridDim.x) {
         const uint32_t r = list[i];
         const uint64_t b0 = offsets[r], b1 = offsets[r + 1];
-        if constexpr (SPLIT) place_read_split<SLOTS, SET_BITS, STATS, WAVES>(db, prm, cx, bases, b0, b1, r, out, stats, 0u);
+        if constexpr (SPLIT) place_read_split<SLOTS, SET_BITS, STATS, WAVES, !BINARY>(db, prm, cx, bases, b0, b1, r, out, stats, 0u);
         else place_read<SLOTS, SET_BITS, STATS, BINARY, WAVES>(db, prm, cx, bases, b0, b1, r, out, stats);
         __syncthreads();
     }
@@ -1184,21 +1313,25 @@ constexpr int CLS_SET_BITS[N_CLASSES] = {9, 11};   // LDS distinct-hit set: 512 
 
 bool use_order(const DbDev& db, uint32_t n_reads) {
     static const bool off = getenv("CLS_NO_ORDER") != nullptr;  // A/B experiments
-    return db.format == FMT_SPLIT && db.direct != nullptr && getenv("CLS_NO_FAST") == nullptr && !off && n_reads >= 4096;
+    return db.format == FMT_SPLIT && db.binary_tree && db.direct != nullptr && getenv("CLS_NO_FAST") == nullptr && !off && n_reads >= 4096;
 }
 bool use_fast(const DbDev& db) {
     static const bool off = getenv("CLS_NO_FAST") != nullptr;  // A/B experiments
-    return db.format == FMT_SPLIT && db.direct != nullptr && !off;
+    return db.format == FMT_SPLIT && db.binary_tree && db.direct != nullptr && !off;
 }
 uint32_t seq_cap_of(const DbDev& db, int c) { return (2 * (64 * CLS_SLOTS[c] / 2 + db.k) + 15) & ~15u; }
 // fast path: L <= 32*SLOTS + k - 1 ascii bytes (+ padding so that the 16-byte packer can over-read)
 uint32_t ascii_cap_of(const DbDev& db, int c) { return (64 * CLS_SLOTS[c] / 2 + db.k + 16 + 15) & ~15u; }
+uint32_t child_ws_stride(const DbDev& db);
+constexpr uint32_t CHILD_LDS_MAX = 256;  // per-child counters of polytomies up to this arity live in LDS
+bool child_in_lds(const DbDev& db) { return child_ws_stride(db) != 0 && child_ws_stride(db) <= CHILD_LDS_MAX; }
 size_t smem_of(const DbDev& db, int c) {
     if (use_fast(db)) {
         const uint32_t ac = ascii_cap_of(db, c);
         return (size_t)WAVES_PER_BLOCK * (ac + 4u * ((ac >> 4) + 2) + (4u << CLS_SET_BITS[c]));
     }
-    return (size_t)WAVES_PER_BLOCK * (seq_cap_of(db, c) + (4u << CLS_SET_BITS[c]) + 4u * 64 * CLS_SLOTS[c]);
+    return (size_t)WAVES_PER_BLOCK * (seq_cap_of(db, c) + (4u << CLS_SET_BITS[c]) + 4u * 64 * CLS_SLOTS[c]) +
+           (child_in_lds(db) ? (size_t)WAVES_PER_BLOCK * 2 * child_ws_stride(db) * 4 : 0);
 }
 
 template <int SLOTS, int SET_BITS>
@@ -1207,8 +1340,10 @@ const void* kernel_of_t(const DbDev& db, bool stats) {
         if (db.addr32) return stats ? (const void*)place_fast_kernel<SLOTS, SET_BITS, true, true> : (const void*)place_fast_kernel<SLOTS, SET_BITS, false, true>;
         return stats ? (const void*)place_fast_kernel<SLOTS, SET_BITS, true, false> : (const void*)place_fast_kernel<SLOTS, SET_BITS, false, false>;
     }
-    if (db.format == FMT_SPLIT)
-        return stats ? (const void*)place_split_kernel<SLOTS, SET_BITS, true> : (const void*)place_split_kernel<SLOTS, SET_BITS, false>;
+    if (db.format == FMT_SPLIT) {
+        if (db.binary_tree) return stats ? (const void*)place_split_kernel<SLOTS, SET_BITS, true, false> : (const void*)place_split_kernel<SLOTS, SET_BITS, false, false>;
+        return stats ? (const void*)place_split_kernel<SLOTS, SET_BITS, true, true> : (const void*)place_split_kernel<SLOTS, SET_BITS, false, true>;
+    }
     const bool binary = db.max_nonleaf_arity <= 2;  // no node has more than two non-LEAF children
     if (stats) return binary ? (const void*)place_wave_kernel<SLOTS, SET_BITS, true, true> : (const void*)place_wave_kernel<SLOTS, SET_BITS, true, false>;
     return binary ? (const void*)place_wave_kernel<SLOTS, SET_BITS, false, true> : (const void*)place_wave_kernel<SLOTS, SET_BITS, false, false>;
@@ -1218,9 +1353,14 @@ const void* kernel_of(const DbDev& db, int c, bool stats) {
 }
 
 uint32_t blk_seq_cap(const DbDev& db) { return (2 * (64 * BLK_WAVES * BLK_SLOTS / 2 + db.k) + 15) & ~15u; }
-size_t blk_smem(const DbDev& db) { return (size_t)blk_seq_cap(db) + (4u << BLK_SET_BITS) + 4u * 64 * BLK_WAVES * BLK_SLOTS + 64; }
+size_t blk_smem(const DbDev& db);
 uint32_t child_ws_stride(const DbDev& db) {
-    return (db.format == FMT_SPLIT || db.max_nonleaf_arity <= 2) ? 0u : ((db.max_nonleaf_arity + 63) & ~63u);
+    if (db.format == FMT_SPLIT) return db.binary_tree ? 0u : ((std::max(db.max_nonleaf_arity, 1u) + 63) & ~63u);
+    return db.max_nonleaf_arity <= 2 ? 0u : ((db.max_nonleaf_arity + 63) & ~63u);
+}
+size_t blk_smem(const DbDev& db) {
+    return (size_t)blk_seq_cap(db) + (4u << BLK_SET_BITS) + 4u * 64 * BLK_WAVES * BLK_SLOTS + 64 +
+           (child_in_lds(db) ? (size_t)2 * child_ws_stride(db) * 4 : 0);
 }
 }  // namespace
 
@@ -1237,16 +1377,16 @@ PlacePlan plan_place(const DbDev& db, uint32_t n_reads, uint32_t n_cu, bool stat
             (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel_of(db, c, stats), 64 * WAVES_PER_BLOCK, smem_of(db, c)) != hipSuccess || per_cu <= 0))
             per_cu = 1;
         uint32_t cap = n_cu * (uint32_t)per_cu;
-        if (child_ws_stride(db)) {  // bound the per-wave child-counter workspace to 128 MiB per class
+        if (child_ws_stride(db) && !child_in_lds(db)) {  // bound the per-wave child-counter workspace to 128 MiB per class
             const uint64_t per_block = (uint64_t)WAVES_PER_BLOCK * 2 * child_ws_stride(db) * 4;
             const uint64_t fit = std::max<uint64_t>(1, (128ull << 20) / per_block);
             if (cap > fit) cap = (uint32_t)fit;
         }
         p.grid[c] = want < cap ? (want ? want : 1) : cap;
-        child_words = std::max<uint64_t>(child_words, (uint64_t)p.grid[c] * WAVES_PER_BLOCK * 2 * child_ws_stride(db));
+        if (!child_in_lds(db)) child_words = std::max<uint64_t>(child_words, (uint64_t)p.grid[c] * WAVES_PER_BLOCK * 2 * child_ws_stride(db));
     }
     p.grid_blk = std::max<uint32_t>(1, std::min<uint32_t>(n_reads, n_cu));  // 1 workgroup per CU (LDS-bound)
-    child_words = std::max<uint64_t>(child_words, (uint64_t)p.grid_blk * 2 * child_ws_stride(db));
+    if (!child_in_lds(db)) child_words = std::max<uint64_t>(child_words, (uint64_t)p.grid_blk * 2 * child_ws_stride(db));
     // workspace (u32 words): [counts 16][list0 n][list1 n][list2 n][keys_in 2n][keys_out 2n][idx_in n][idx_out n][sort temp][child counters]
     p.ordered = use_order(db, n_reads);
     uint64_t w = 16 + 3 * (uint64_t)n_reads;
@@ -1274,7 +1414,7 @@ hipError_t launch_place(const DbDev& db, const PlaceParams& prm, const PlacePlan
     if (n_reads == 0) return hipSuccess;
     uint32_t* counts = d_ws;
     uint32_t* lists[3] = {d_ws + 16, d_ws + 16 + n_reads, d_ws + 16 + 2 * (size_t)n_reads};
-    uint32_t* child_ws = child_ws_stride(db) ? d_ws + plan.child_off_words : nullptr;
+    uint32_t* child_ws = (child_ws_stride(db) && !child_in_lds(db)) ? d_ws + plan.child_off_words : nullptr;
     hipError_t e = hipMemsetAsync(counts, 0, 64, stream);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(classify_kernel, dim3((n_reads + 255) / 256), dim3(256), 0, stream, d_offsets, n_reads, db.k,
@@ -1329,10 +1469,12 @@ hipError_t launch_place(const DbDev& db, const PlaceParams& prm, const PlacePlan
             return;
         }
         if (db.format == FMT_SPLIT) {
-            if (st) hipLaunchKernelGGL((place_split_kernel<SLOTS, SET_BITS, true>), grid, block, smem, stream, db, prm, d_bases, d_offsets,
-                                       lists[c], counts + c, d_out, d_stats, seq_cap, profile_stop);
-            else hipLaunchKernelGGL((place_split_kernel<SLOTS, SET_BITS, false>), grid, block, smem, stream, db, prm, d_bases, d_offsets,
-                                    lists[c], counts + c, d_out, d_stats, seq_cap, profile_stop);
+#define CLS_LAUNCH_SPLIT(ST, PO)                                                                                        \
+    hipLaunchKernelGGL((place_split_kernel<SLOTS, SET_BITS, ST, PO>), grid, block, smem, stream, db, prm, d_bases, d_offsets, \
+                       lists[c], counts + c, d_out, d_stats, seq_cap, profile_stop, child_ws, ws_stride)
+            if (db.binary_tree) { if (st) CLS_LAUNCH_SPLIT(true, false); else CLS_LAUNCH_SPLIT(false, false); }
+            else { if (st) CLS_LAUNCH_SPLIT(true, true); else CLS_LAUNCH_SPLIT(false, true); }
+#undef CLS_LAUNCH_SPLIT
             return;
         }
 #define CLS_LAUNCH(ST, BI)                                                                                          \
@@ -1359,7 +1501,8 @@ hipError_t launch_place(const DbDev& db, const PlaceParams& prm, const PlacePlan
         hipLaunchKernelGGL(kfn, grid, block, smem, stream, db, prm, d_bases, d_offsets, lists[2], counts + 2, d_out, d_stats,    \
                            seq_cap, child_ws, ws_stride);                                                                        \
     } while (0)
-        if (db.format == FMT_SPLIT) { if (st) CLS_LAUNCH_BLK(true, true, true); else CLS_LAUNCH_BLK(false, true, true); }
+        if (db.format == FMT_SPLIT && db.binary_tree) { if (st) CLS_LAUNCH_BLK(true, true, true); else CLS_LAUNCH_BLK(false, true, true); }
+        else if (db.format == FMT_SPLIT) { if (st) CLS_LAUNCH_BLK(true, false, true); else CLS_LAUNCH_BLK(false, false, true); }
         else if (binary) { if (st) CLS_LAUNCH_BLK(true, true, false); else CLS_LAUNCH_BLK(false, true, false); }
         else { if (st) CLS_LAUNCH_BLK(true, false, false); else CLS_LAUNCH_BLK(false, false, false); }
 #undef CLS_LAUNCH_BLK

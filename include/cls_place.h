@@ -166,6 +166,10 @@ typedef struct cls_db_info {
     uint64_t hbm_bytes;        /* device bytes held by the handle                */
     uint32_t max_read_kmers;   /* per-read k-mer capacity of the kernels         */
     int32_t device;
+    uint32_t format;           /* 0: sorted lists (some node set is not closed under `parent`); 1: split-tree records */
+    uint32_t binary_tree;      /* 1: every clade has zero or two children        */
+    uint32_t direct_table;     /* 1: 2-bit-code direct table in use (k <= 15)    */
+    uint32_t pad_;
 } cls_db_info;
 
 /* Number of usable HIP devices (0 if none). */

@@ -65,3 +65,32 @@ def ragged_reads(rng, synth, n, min_len, max_len, err=0.02, frac_random=0.05, lo
         offs.append(offs[-1] + L)
     bases = np.concatenate(parts) if parts else np.zeros(0, dtype=np.uint8)
     return bases, np.array(offs, dtype=np.uint64)
+
+
+def star_of_cherries(n_cherries: int, seq_len: int = 60, k: int = 7, m: int = 3, seed: int = 0):
+    """A root with `n_cherries` internal children of two leaves each (a polytomy whose non-LEAF arity is
+    n_cherries), indexed like `cls build-db` does.  -> (FlatDb, list of leaf sequences)"""
+    from oracle import oracle_literal as lit
+
+    rng = np.random.default_rng(seed)
+    alphabet = np.frombuffer(b"ACGT", dtype=np.uint8)
+    root = dict(id=0, parent=None, kind="ROOT", children=[])
+    km = lit.KmersMap(k, m)
+    seqs = []
+    nid = 1
+    for _ in range(n_cherries):
+        base = alphabet[rng.integers(0, 4, seq_len)]
+        node = dict(id=nid, parent=0, kind="NODE", children=[])
+        nid += 1
+        for _leaf in range(2):
+            sq = base.copy()
+            pos = rng.integers(0, seq_len, 2)
+            sq[pos] = alphabet[rng.integers(0, 4, 2)]
+            seq = bytes(sq).decode()
+            seqs.append(seq)
+            node["children"].append(dict(id=nid, parent=node["id"], kind="LEAF"))
+            for kmer, h in km.build_kmer_from_string(seq):
+                km.insert_or_append_kmer_hash(kmer, h, {0, node["id"], nid})
+            nid += 1
+        root["children"].append(node)
+    return FlatDb.from_nested(root, k, m, km.map), seqs

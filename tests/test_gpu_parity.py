@@ -103,6 +103,39 @@ def test_mixed_read_lengths_use_both_kernels(collapse):
     _check(drop_random_nodes(s.flat, 0.2, seed=4), bases, offsets, {})
 
 
+def test_huge_polytomy_uses_global_child_counters():
+    """A root with 300 internal children (non-LEAF arity > 256): the per-child counters leave LDS for the
+    global scratch area; the same shape at arity 40 stays in LDS."""
+    from tests.helpers import star_of_cherries
+    for n_cherries in (300, 40):
+        flat, seqs = star_of_cherries(n_cherries)
+        rng = np.random.default_rng(3)
+        picks = rng.integers(0, len(seqs), 400)
+        reads = [seqs[i][int(a):int(a) + 30] for i, a in zip(picks, rng.integers(0, 25, 400))]
+        bases = np.frombuffer("".join(reads).encode(), dtype=np.uint8)
+        offsets = np.concatenate([[0], np.cumsum([len(r) for r in reads])]).astype(np.uint64)
+        with engine.PlacementDb(flat, device=0) as db:
+            assert db.info.max_nonleaf_arity == n_cherries and db.info.format == 1 and db.info.binary_tree == 0
+        for f in (flat, drop_random_nodes(flat, 0.1, seed=5)):
+            for kw in PARAM_SETS[:2]:
+                got = _check(f, bases, offsets, kw)
+        assert (got["status"] == _abi.IDENTITY_FOUND).sum() > 100
+
+
+def test_index_format_selection():
+    """Which device layout / kernels an index gets."""
+    cases = [
+        (SynthDb(60, 300, 8, 4), None, (1, 1, 1)),                      # closed sets, binary tree, k <= 15: fast path
+        (SynthDb(60, 300, 17, 4), None, (1, 1, 0)),                     # k > 15: split records, murmur probe path
+        (SynthDb(60, 300, 8, 4, collapse_prob=0.4), None, (1, 0, 0)),   # polytomies: split records, child walk
+        (SynthDb(60, 300, 8, 4), 0.2, (0, 1, 0)),                       # a node set that is not closed: sorted lists
+    ]
+    for s, drop, want in cases:
+        flat = drop_random_nodes(s.flat, drop, seed=2) if drop else s.flat
+        with engine.PlacementDb(flat, device=0) as db:
+            assert (db.info.format, db.info.binary_tree, db.info.direct_table) == want
+
+
 def test_empty_batch_and_offsets_base():
     s = SynthDb(50, 300, 8, 4)
     with engine.PlacementDb(s.flat, device=0) as db:

@@ -1,1 +1,4 @@
-for b in 2 3 4; do CLS_BLOCKS_PER_CU=$b timeout -k 10 300 python bench.py --steps 10 --warmup 2 --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('blocks/CU $b', d['value'], d['ms_per_step'], d['roofline']['kernel_ms'])"; done
+timeout -k 10 600 python -m pytest tests -x -q -m gpu 2>&1 | tail -5
+timeout -k 10 300 python tools/poly_probe.py 2>&1 | grep -v amdgpu
+CLS_FORCE_LIST=1 timeout -k 10 300 python tools/poly_probe.py 2>&1 | grep -v amdgpu
+timeout -k 10 300 python tools/poly_probe.py 20 2>&1 | grep -v amdgpu
