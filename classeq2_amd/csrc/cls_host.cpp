@@ -24,6 +24,7 @@
 #include <vector>
 
 #include "cls_host.h"
+#include "cls_host_internal.h"
 #include "cls_json.h"
 
 namespace {
@@ -508,6 +509,37 @@ std::string with_extension(const std::string& path, const char* ext) {  // PathB
 }  // namespace
 
 extern "C" const char* cls_host_last_error(void) { return g_err.c_str(); }
+
+int cls_host_fail(int code, const std::string& msg) { return fail(code, msg); }
+
+void cls_tree_visit_leaves(const cls_tree* t, const std::function<void(const char*, const std::vector<uint64_t>&)>& fn) {
+    struct Fr { const Clade* c; size_t next; };
+    std::vector<Fr> st{{&t->root, 0}};
+    std::vector<uint64_t> path{t->root.id};
+    if (t->root.kind == CLS_KIND_LEAF) fn(t->root.has_name ? t->root.name.c_str() : nullptr, path);
+    while (!st.empty()) {
+        Fr& f = st.back();
+        if (f.c->kind == CLS_KIND_LEAF || f.next >= f.c->children.size()) { st.pop_back(); path.pop_back(); continue; }  // leaves are not descended into
+        const Clade* ch = &f.c->children[f.next++];
+        path.push_back(ch->id);
+        if (ch->kind == CLS_KIND_LEAF) fn(ch->has_name ? ch->name.c_str() : nullptr, path);
+        st.push_back({ch, 0});
+    }
+}
+
+void cls_tree_set_kmers_map(cls_tree* t, uint64_t k, uint64_t m, std::vector<uint64_t>&& bucket_key,
+                            std::vector<uint64_t>&& bucket_kmer_off, std::vector<uint64_t>&& kmer_hash,
+                            std::vector<uint64_t>&& kmer_node_off, std::vector<uint64_t>&& node_ids) {
+    t->has_kmers = true;
+    t->k_size = k;
+    t->m_size = m;
+    t->bucket_key = std::move(bucket_key);
+    t->bucket_kmer_off = std::move(bucket_kmer_off);
+    if (t->bucket_kmer_off.empty()) t->bucket_kmer_off.push_back(0);
+    t->kmer_hash = std::move(kmer_hash);
+    t->kmer_node_off = std::move(kmer_node_off);
+    t->node_ids = std::move(node_ids);
+}
 
 extern "C" void cls_tree_free(cls_tree* t) { delete t; }
 

@@ -26,7 +26,7 @@ EXPORTS = [
     "cls_version",
 ]
 HOST_EXPORTS = [
-    "cls_tree_load_json", "cls_tree_free", "cls_tree_set_annotations_yaml", "cls_tree_desc", "cls_serialize_results",
+    "cls_tree_load_json", "cls_tree_free", "cls_tree_set_annotations_yaml", "cls_tree_build_kmers_map", "cls_tree_desc", "cls_serialize_results",
     "cls_host_free", "cls_place_sequences", "cls_host_last_error",
 ]
 FORMAT_YAML, FORMAT_JSONL = 0, 1
@@ -79,6 +79,8 @@ def lib():
         L.cls_tree_free.restype = None
         L.cls_tree_set_annotations_yaml.argtypes = [vp, C.c_char_p]
         L.cls_tree_set_annotations_yaml.restype = i32
+        L.cls_tree_build_kmers_map.argtypes = [vp, C.c_char_p, C.c_size_t, C.c_uint64, C.c_uint64, u32]
+        L.cls_tree_build_kmers_map.restype = i32
         L.cls_tree_desc.argtypes = [vp, C.POINTER(_abi.DbDesc)]
         L.cls_tree_desc.restype = i32
         L.cls_serialize_results.argtypes = [vp, C.c_char_p, vp, u32, vp, i32, C.POINTER(vp), C.POINTER(C.c_size_t),
@@ -222,6 +224,12 @@ class Tree:
             self.close()
         except Exception:
             pass
+
+    def build_kmers_map(self, msa_text: bytes, k_size: int, m_size: int = 4, reference_header_shift: bool = True,
+                        forward_only: bool = False) -> None:
+        """`cls build-db` (map_kmers_to_tree) on this tree; see include/cls_host.h."""
+        flags = (1 if reference_header_shift else 0) | (2 if forward_only else 0)
+        _check_host(lib().cls_tree_build_kmers_map(self._h, msa_text, len(msa_text), k_size, m_size, flags))
 
     def flat(self) -> FlatDb:
         d = _abi.DbDesc()

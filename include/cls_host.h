@@ -28,6 +28,13 @@ int cls_tree_load_json(const char* path, cls_tree** out);
 void cls_tree_free(cls_tree* t);
 /* `-a/--annotations-file-path` of `cls place` (ports/cli/src/cmds/place_sequences.rs:137-144). */
 int cls_tree_set_annotations_yaml(cls_tree* t, const char* path);
+/* `cls build-db` on an already parsed tree: map_kmers_to_tree (core/src/use_cases/build_database/mod.rs:26-181).
+ * `msa_text` is the multi-FASTA whose headers name the tree's leaves.  Replaces the tree's k-mer map. */
+#define CLS_BUILD_REFERENCE_HEADER_SHIFT 1u /* file record i's k-mers under header i+1, never index the last record
+                                             * (what the reference does, build_database/mod.rs:93-116) */
+#define CLS_BUILD_FORWARD_ONLY 2u           /* forward k-mers only (builds older than the reverse-complement change) */
+int cls_tree_build_kmers_map(cls_tree* t, const char* msa_text, size_t msa_len, uint64_t k_size, uint64_t m_size,
+                             uint32_t flags);
 /* Borrowed flat view for cls_db_create(); valid while `t` lives. */
 int cls_tree_desc(const cls_tree* t, cls_db_desc* d);
 
