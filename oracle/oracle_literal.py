@@ -299,8 +299,17 @@ def status_to_string(status) -> str:
     return f"Inconclusive: {status[2]}"
 
 
+def rust_as_usize(x: float) -> int:
+    """Rust `f64 as usize`: saturating, NaN -> 0."""
+    if x != x or x <= 0:
+        return 0
+    return min(int(x), (1 << 64) - 1)
+
+
 def rust_round(x: float) -> float:
-    """f64::round: half away from zero (x >= 0 on this path)."""
+    """f64::round: half away from zero (x >= 0 on this path); NaN stays NaN."""
+    if x != x or x in (float("inf"), float("-inf")):
+        return x
     r = math.floor(x)
     if x - r >= 0.5:
         r += 1
@@ -385,7 +394,7 @@ def place_sequence(
     expected_min_clade_coverage = rust_round(query_kmers_len * min_match_coverage)
     introspection_coverage = sum(len(v) for v in introspection_kmers.map.values())
     tr.introspection_coverage = introspection_coverage
-    if introspection_coverage < int(expected_min_clade_coverage):
+    if introspection_coverage < rust_as_usize(expected_min_clade_coverage):
         return ("Unclassifiable", f"Insufficient kmers coverage: {introspection_coverage}")
     # :279-601
     while True:

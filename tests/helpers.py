@@ -12,6 +12,15 @@ PARAM_SETS = [
     dict(max_iterations=2),
     dict(max_iterations=0),
 ]
+# Option<> corner values: clamping (place_sequence.rs:67-75), NaN coverage (`as usize` -> 0), negative iteration caps
+ODD_PARAM_SETS = [
+    dict(min_match_coverage=7.5),
+    dict(min_match_coverage=-3.0),
+    dict(min_match_coverage=float("nan")),
+    dict(min_match_coverage=0.5, remove_intersection=True, max_iterations=1000000),
+    dict(max_iterations=-4),
+    dict(max_iterations=1),
+]
 
 
 def records_equal(a: np.ndarray, b: np.ndarray):

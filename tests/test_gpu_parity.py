@@ -5,7 +5,7 @@ import pytest
 from classeq2_amd import _abi, engine
 from classeq2_amd.synth import SynthDb
 from oracle import oracle_port as op
-from tests.helpers import PARAM_SETS, describe, drop_random_nodes, ragged_reads, records_equal, stats_equal
+from tests.helpers import ODD_PARAM_SETS, PARAM_SETS, describe, drop_random_nodes, ragged_reads, records_equal, stats_equal
 
 pytestmark = pytest.mark.gpu
 
@@ -120,6 +120,35 @@ def test_huge_polytomy_uses_global_child_counters():
             for kw in PARAM_SETS[:2]:
                 got = _check(f, bases, offsets, kw)
         assert (got["status"] == _abi.IDENTITY_FOUND).sum() > 100
+
+
+def test_option_corner_values():
+    for s in (SynthDb(80, 300, 9, 4), SynthDb(80, 300, 9, 4, collapse_prob=0.4)):
+        bases, offsets, _ = s.reads(600, 100, frac_random=0.05, err=0.03)
+        for kw in ODD_PARAM_SETS:
+            _check(s.flat, bases, offsets, kw)
+
+
+def test_concurrent_host_calls_are_reentrant():
+    """cls_place_batch from several threads on one handle (own stream + scratch per call)."""
+    import threading
+    s = SynthDb(200, 500, 10, 4)
+    bases, offsets, _ = s.reads(6000, 150)
+    want = op.OraclePort(s.flat).place_batch(bases, offsets, threads=8)
+    results, errors = {}, []
+    with engine.PlacementDb(s.flat, device=0) as db:
+        def work(i):
+            try:
+                for _ in range(3):
+                    results[i] = db.place_batch(bases, offsets)
+            except Exception as e:  # pragma: no cover
+                errors.append(e)
+        th = [threading.Thread(target=work, args=(i,)) for i in range(4)]
+        [t.start() for t in th]
+        [t.join() for t in th]
+    assert not errors, errors
+    for i in range(4):
+        assert len(records_equal(results[i], want)) == 0
 
 
 def test_index_format_selection():

@@ -6,7 +6,7 @@ import pytest
 from classeq2_amd.synth import SynthDb
 from oracle import oracle_literal as lit
 from oracle import oracle_port as op
-from tests.helpers import PARAM_SETS, drop_random_nodes, ragged_reads, records_equal
+from tests.helpers import ODD_PARAM_SETS, PARAM_SETS, drop_random_nodes, ragged_reads, records_equal
 
 # Known answers printed in the reference's own docs (docs/book/02-build-db.md:181-196):
 # minimizer keys + k-mer hashes of the bsub-gyrB model (k=35, m=4); the two
@@ -56,7 +56,7 @@ def test_port_matches_literal(case):
     tree = op.flat_to_literal(s.flat)
     port = op.OraclePort(s.flat)
     bases, offsets, _ = s.reads(150, rdlen, frac_random=0.05, err=0.02)
-    for kw in PARAM_SETS:
+    for kw in PARAM_SETS + (ODD_PARAM_SETS if nl == 60 else []):
         want = op.literal_place_batch(tree, bases, offsets, **kw)
         got = port.place_batch(bases, offsets, op.make_params(**kw), threads=2)
         assert len(records_equal(got, want)) == 0, kw
