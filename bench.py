@@ -208,7 +208,7 @@ def main():
                 "algorithmic_bytes_per_read": alg_bytes / per_gpu,
             },
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # rank 0 at N=1 only
             line["cpu_baseline"] = cpu_baseline(synth, cfg)
         print(json.dumps(line), flush=True)
     if world > 1:
