@@ -945,7 +945,8 @@ struct FastCtx {
 // Returns false if the read holds a character other than ACGT.
 template <int SLOTS, int SET_BITS, bool ADDR32>
 __device__ __forceinline__ bool fast_front(const DbDev& db, const FastCtx& cx, const uint8_t* __restrict__ bases, uint64_t b0,
-                                           uint32_t L, uint32_t nf, uint32_t nk, uint32_t (&off)[SLOTS], uint32_t (&meta)[SLOTS]) {
+                                           uint32_t L, uint32_t nf, uint32_t nk, uint32_t (&off)[SLOTS], uint32_t (&meta)[SLOTS],
+                                           uint32_t sample_shift = 32, bool canonical = false) {
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t k = db.k;
     bool bad = false;
@@ -991,10 +992,13 @@ __device__ __forceinline__ bool fast_front(const DbDev& db, const FastCtx& cx, c
         uint32_t rcc = __builtin_bitreverse32(code ^ (0xAAAAAAAAu & kmask));
         rcc = ((rcc >> 1) & 0x55555555u) | ((rcc & 0x55555555u) << 1);
         rcc >>= (32 - 2 * k);
-        code = rc ? rcc : code;
-        const uint2 e = ldx<uint2, ADDR32>(direct, valid ? code : 0u);
-        off[s] = valid ? e.x : 0u;
-        meta[s] = valid ? e.y : 0xFFFFFFFFu;
+        code = canonical ? (rcc < code ? rcc : code) : (rc ? rcc : code);  // canonical: the same entry whichever strand was read
+        // sample_shift < 32: look up only the k-mers whose scrambled code has its top bits clear (a content-
+        // based sample, the same k-mers in every read that contains them); 32 = all
+        const bool take = valid && (sample_shift >= 32 || ((code * 0x9E3779B1u) >> sample_shift) == 0);
+        const uint2 e = ldx<uint2, ADDR32>(direct, take ? code : 0u);
+        off[s] = take ? e.x : 0u;
+        meta[s] = take ? e.y : 0xFFFFFFFFu;
     }
     return true;
 }
@@ -1205,7 +1209,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void order_key_kernel(DbDev d
                                                                        const uint64_t* __restrict__ offsets, uint32_t n_reads,
                                                                        uint64_t* __restrict__ keys, uint32_t* __restrict__ idx,
                                                                        uint32_t ascii_cap, uint32_t tip_bits, uint32_t spec_lg,
-                                                                       uint32_t block_shift) {
+                                                                       uint32_t block_shift, uint32_t sample_shift, uint32_t fwd_only) {
     extern __shared__ __align__(16) uint8_t smem[];
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const uint32_t packed_words = (ascii_cap >> 4) + 2;
@@ -1222,7 +1226,9 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void order_key_kernel(DbDev d
         if (L64 >= db.k && 2 * (L64 - db.k + 1) <= (uint64_t)(64 * SLOTS)) {
             const uint32_t L = (uint32_t)L64, nf = L - db.k + 1, nk = 2 * nf;
             uint32_t off[SLOTS], meta[SLOTS];
-            if (fast_front<SLOTS, 0, ADDR32>(db, cx, bases, b0, L, nf, nk, off, meta)) {
+            // one lookup per window, of the smaller of the k-mer and its reverse complement: an index built from
+            // both strands files the two under the same leaves, and the key then does not depend on the strand read
+            if (fast_front<SLOTS, 0, ADDR32>(db, cx, bases, b0, L, nf, fwd_only ? nf : nk, off, meta, sample_shift, fwd_only != 0)) {
                 // candidates: k-mers present in the index that are specific to a small clade (few tips);
                 // the tip bound is widened until a handful qualify (finally: every k-mer present)
                 uint32_t cand = 0, n_cand = 0;
@@ -1437,14 +1443,16 @@ hipError_t launch_place(const DbDev& db, const PlaceParams& prm, const PlacePlan
         uint32_t tip_bits = 1;
         while (tip_bits < 32 && (1u << tip_bits) < db.n_nodes) ++tip_bits;
         static const uint32_t spec_lg = [] { const char* v = getenv("CLS_ORDER_SPEC_LG"); return v ? (uint32_t)atoi(v) : 3u; }();
+        static const uint32_t fwd_only = [] { const char* v = getenv("CLS_ORDER_BOTH_STRANDS"); return v ? 0u : 1u; }();
+        static const uint32_t sample_shift = [] { const char* v = getenv("CLS_ORDER_SAMPLE_SHIFT"); return v ? (uint32_t)atoi(v) : 32u; }();
         static const uint32_t block_shift = [] { const char* v = getenv("CLS_ORDER_BLOCK_SHIFT"); return v ? (uint32_t)atoi(v) : 2u; }();
         const size_t smem_k = (size_t)WAVES_PER_BLOCK * (ac + 4u * ((ac >> 4) + 2) + 16u);
         if (db.addr32)
             hipLaunchKernelGGL((order_key_kernel<CLS_SLOTS[0], true>), dim3(plan.grid[0]), dim3(64 * WAVES_PER_BLOCK), smem_k, stream, db,
-                               d_bases, d_offsets, n_reads, keys_in, idx_in, ac, tip_bits, spec_lg, block_shift);
+                               d_bases, d_offsets, n_reads, keys_in, idx_in, ac, tip_bits, spec_lg, block_shift, sample_shift, fwd_only);
         else
             hipLaunchKernelGGL((order_key_kernel<CLS_SLOTS[0], false>), dim3(plan.grid[0]), dim3(64 * WAVES_PER_BLOCK), smem_k, stream, db,
-                               d_bases, d_offsets, n_reads, keys_in, idx_in, ac, tip_bits, spec_lg, block_shift);
+                               d_bases, d_offsets, n_reads, keys_in, idx_in, ac, tip_bits, spec_lg, block_shift, sample_shift, fwd_only);
         e = sort_pairs(d_ws + plan.sort_off_words, plan.sort_bytes, keys_in, keys_out, idx_in, idx_out, n_reads, ORDER_KEY_BITS, stream);
         if (e != hipSuccess) return e;
         list0 = idx_out;

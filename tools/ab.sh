@@ -1,4 +1,2 @@
-timeout -k 10 600 python -m pytest tests -x -q -m gpu 2>&1 | tail -5
-timeout -k 10 300 python tools/poly_probe.py 2>&1 | grep -v amdgpu
-CLS_FORCE_LIST=1 timeout -k 10 300 python tools/poly_probe.py 2>&1 | grep -v amdgpu
-timeout -k 10 300 python tools/poly_probe.py 20 2>&1 | grep -v amdgpu
+timeout -k 10 600 python -m pytest tests -x -q -m gpu 2>&1 | tail -2
+for v in "A=1" "CLS_ORDER_SAMPLE_SHIFT=31"; do env $v timeout -k 10 200 python bench.py --steps 10 --warmup 2 --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$v', d['value'], d['ms_per_step'], d['roofline']['kernel_ms'])"; done
