@@ -66,6 +66,7 @@ struct cls_db {
     void* d_bucket_key = nullptr;
     void* d_direct = nullptr;
     std::mutex ws_mu;
+    uint64_t max_read_len = 16384;  // what the device-buffer entry provisions its long-read slices for
     double kernel_ms_sum = 0.0;
     uint64_t kernel_launches = 0;
     std::vector<Workspace> ws;  // per-call scratch (class lists, child counters), recycled once their launch has finished
@@ -162,7 +163,7 @@ extern "C" int cls_db_create(const cls_db_desc* d, int device, cls_db** out) {
         i.table_slots = E.table.size();
         i.postings_words = E.postings.size();
         i.hbm_bytes = E.nodes.size() * sizeof(cls::DNode) + E.table.size() * sizeof(cls::Slot) + E.postings.size() * 4 + E.bucket_key.size() * 8 + E.direct.size() * 4;
-        i.max_read_kmers = cls::MAX_READ_KMERS;
+        i.max_read_kmers = (uint32_t)std::max<uint64_t>(cls::MAX_READ_KMERS, 2 * db->max_read_len);
         i.device = device;
         i.format = E.format;
         i.binary_tree = E.strictly_binary ? 1u : 0u;
@@ -229,28 +230,49 @@ static int acquire_ws(cls_db* db, uint64_t words, size_t* slot) {
     return CLS_OK;
 }
 
+// Longest read (bases) any kernel is provisioned for: 2^25 bases = 2^26 k-mers per read.
+static constexpr uint64_t HARD_MAX_READ_LEN = 1ull << 25;
+
+extern "C" int cls_db_set_max_read_len(cls_db* db, uint64_t n_bases) {
+    if (!db) return fail(CLS_E_INVALID_ARG, "cls_db_set_max_read_len: null handle");
+    if (n_bases > HARD_MAX_READ_LEN) return fail(CLS_E_INVALID_ARG, "cls_db_set_max_read_len: at most 2^25 bases per read");
+    std::lock_guard<std::mutex> g(db->ws_mu);
+    db->max_read_len = n_bases;
+    db->info.max_read_kmers = (uint32_t)std::max<uint64_t>(cls::MAX_READ_KMERS, 2 * n_bases);
+    return CLS_OK;
+}
+
+// `long_cap` = k-mers per read to provision beyond the register-resident kernels (0: none), `n_long` = how many
+// such reads the batch can hold at most.
+static int place_device(cls_db* db, const void* d_bases, const void* d_offsets, uint32_t n, const cls_params* params,
+                        void* d_out, void* d_stats, hipStream_t stream, uint32_t long_cap, uint32_t n_long) {
+    const cls::PlaceParams prm = resolve(params);
+    const cls::PlacePlan plan = cls::plan_place(db->dev, n, (uint32_t)db->n_cu, d_stats != nullptr, long_cap, n_long);
+    size_t slot = 0;
+    int rc = acquire_ws(db, (plan.ws_bytes + 3) / 4, &slot);
+    if (rc != CLS_OK) return rc;
+    hipError_t e = cls::launch_place(db->dev, prm, plan, (const uint8_t*)d_bases, (const uint64_t*)d_offsets, n,
+                                     (cls_placement*)d_out, (cls_query_stats*)d_stats, db->ws[slot].ptr, stream,
+                                     db->ws[slot].t0, db->ws[slot].t1);
+    {
+        std::lock_guard<std::mutex> g(db->ws_mu);
+        db->ws[slot].timed = (e == hipSuccess);
+        if (hipEventRecord(db->ws[slot].done, stream) != hipSuccess) { db->ws[slot].busy = false; db->ws[slot].timed = false; }
+    }
+    if (e != hipSuccess) return fail(CLS_E_HIP, std::string("kernel launch failed: ") + hipGetErrorString(e));
+    return CLS_OK;
+}
+
 extern "C" int cls_place_batch_device(cls_db* db, const void* d_bases, const void* d_offsets, uint32_t n,
                                       const cls_params* params, void* d_out, void* d_stats, void* hip_stream) {
     if (!db) return fail(CLS_E_INVALID_ARG, "cls_place_batch_device: null handle");
     if (n == 0) return CLS_OK;
     if (!d_offsets || !d_out) return fail(CLS_E_INVALID_ARG, "cls_place_batch_device: null buffer");
     try {
-        hipStream_t stream = (hipStream_t)hip_stream;
-        const cls::PlaceParams prm = resolve(params);
-        const cls::PlacePlan plan = cls::plan_place(db->dev, n, (uint32_t)db->n_cu, d_stats != nullptr);
-        size_t slot = 0;
-        int rc = acquire_ws(db, (plan.ws_bytes + 3) / 4, &slot);
-        if (rc != CLS_OK) return rc;
-        hipError_t e = cls::launch_place(db->dev, prm, plan, (const uint8_t*)d_bases, (const uint64_t*)d_offsets, n,
-                                         (cls_placement*)d_out, (cls_query_stats*)d_stats, db->ws[slot].ptr, stream,
-                                         db->ws[slot].t0, db->ws[slot].t1);
-        {
-            std::lock_guard<std::mutex> g(db->ws_mu);
-            db->ws[slot].timed = (e == hipSuccess);
-            if (hipEventRecord(db->ws[slot].done, stream) != hipSuccess) { db->ws[slot].busy = false; db->ws[slot].timed = false; }
-        }
-        if (e != hipSuccess) return fail(CLS_E_HIP, std::string("kernel launch failed: ") + hipGetErrorString(e));
-        return CLS_OK;
+        uint64_t max_len;
+        { std::lock_guard<std::mutex> g(db->ws_mu); max_len = db->max_read_len; }
+        // the read lengths are only known on the device: provision for the handle's limit
+        return place_device(db, d_bases, d_offsets, n, params, d_out, d_stats, (hipStream_t)hip_stream, (uint32_t)(2 * max_len), n);
     } catch (...) {
         return fail(CLS_E_INTERNAL, "cls_place_batch_device: unknown exception");
     }
@@ -323,9 +345,17 @@ static int place_host(cls_db* db, const char* bases, const uint64_t* offsets, ui
             }
             rel.resize((size_t)cnt + 1);
             for (uint32_t i = 0; i <= cnt; ++i) rel[i] = offsets[first + i] - offsets[first];
+            // reads beyond the register-resident kernels: provision exactly what this chunk needs
+            uint64_t longest = 0;
+            uint32_t n_long = 0;
+            for (uint32_t i = 0; i < cnt; ++i) {
+                const uint64_t len = rel[i + 1] - rel[i];
+                const uint64_t nk = len < db->dev.k ? 0 : 2 * (len - db->dev.k + 1);
+                if (nk > cls::MAX_READ_KMERS) { ++n_long; longest = std::max(longest, std::min(len, HARD_MAX_READ_LEN)); }
+            }
             if (nbytes) CLS_TRY(hipMemcpyAsync(d_bases, bases + offsets[first], nbytes, hipMemcpyHostToDevice, stream));
             CLS_TRY(hipMemcpyAsync(d_off, rel.data(), ((size_t)cnt + 1) * 8, hipMemcpyHostToDevice, stream));
-            rc = cls_place_batch_device(db, d_bases, d_off, cnt, params, d_out, d_stats, stream);
+            rc = place_device(db, d_bases, d_off, cnt, params, d_out, d_stats, stream, (uint32_t)(2 * longest), n_long);
             if (rc != CLS_OK) { cleanup(); return rc; }
             CLS_TRY(hipMemcpyAsync(out + first, d_out, (size_t)cnt * sizeof(cls_placement), hipMemcpyDeviceToHost, stream));
             if (stats) CLS_TRY(hipMemcpyAsync(stats + first, d_stats, (size_t)cnt * sizeof(cls_query_stats), hipMemcpyDeviceToHost, stream));

@@ -15,9 +15,17 @@ struct PlacePlan {
     uint64_t sort_off_words;   // radix-sort scratch
     size_t sort_bytes;
     uint64_t child_off_words;  // offset of the child-counter area inside the workspace
+    uint32_t grid_long;        // workgroups of the long-read class (0: none in this launch)
+    uint32_t long_cap;         // k-mers per read its slices hold (0: reads beyond MAX_READ_KMERS are refused)
+    uint32_t long_arity;       // child counters per slice (padded arity)
+    uint64_t long_set;         // entries of the distinct-hit set (power of two)
+    uint64_t long_stride_words;
+    uint64_t long_off_words;
     uint64_t ws_bytes;         // device scratch the launch needs
 };
-PlacePlan plan_place(const DbDev& db, uint32_t n_reads, uint32_t n_cu, bool stats);
+// `long_cap`: k-mer capacity wanted for reads beyond MAX_READ_KMERS (0 = refuse them), `n_long`: how many
+// such reads the batch may hold (bounds the number of workspace slices).
+PlacePlan plan_place(const DbDev& db, uint32_t n_reads, uint32_t n_cu, bool stats, uint32_t long_cap, uint32_t n_long);
 // Asynchronous on `stream`; all pointers are device pointers; `d_ws` holds plan.ws_bytes.
 // `ev_start`/`ev_stop` (may be null) are recorded around the class-0 placement kernel.
 hipError_t launch_place(const DbDev& db, const PlaceParams& prm, const PlacePlan& plan, const uint8_t* d_bases,

@@ -1271,13 +1271,342 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void order_key_kernel(DbDev d
     }
 }
 
+// ---- long reads: one WORKGROUP per read, per-k-mer state in global scratch ---------------------------
+// Reads with more k-mers than the register-resident kernels hold (marker genes are a few kb, BASELINE
+// config 5 has 10 kb reads).  Same algorithm, written one k-mer per thread and trip: the read is not
+// staged (bases are re-read from memory per k-mer), the distinct-hash set, the per-k-mer state and the
+// per-child counters live in a per-workgroup slice of the workspace, and after every level the surviving
+// k-mers are compacted into the other of two state buffers, so a level costs time in proportion to the
+// k-mers still below the current clade.  FMT_SPLIT walks a k-mer's own chain of occupied children (cost
+// per k-mer = children it has tips under, whatever the clade's arity); FMT_LIST tests every child.
+constexpr int LONG_THREADS = 256;
+constexpr int LONG_STATE_WORDS = 5;  // u32 arrays per state buffer: SPLIT {vlo, vhi, x}; LIST {lo, hi, vlo, vhi, closed}
+
+struct LongSh {
+    uint32_t acc[4];
+    unsigned long long acc64;
+    uint32_t n_next;     // survivors appended to the next state buffer
+    uint32_t n_pass, n_best, best_row;
+    int32_t best_diff, best_one, best_rest;
+};
+
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v);
+
+// position of this thread's element in a list that all threads of the workgroup append to (wave-aggregated)
+__device__ __forceinline__ uint32_t append_slot(bool keep, uint32_t* counter) {
+    const uint32_t lane = threadIdx.x & 63;
+    const uint64_t m = __ballot(keep);
+    if (!m) return 0;
+    const int leader = __ffsll((unsigned long long)m) - 1;
+    uint32_t base = 0;
+    if ((int)lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(m));
+    base = __shfl(base, leader);
+    return base + (uint32_t)__popcll(m & ((1ull << lane) - 1));
+}
+
+template <int N>
+__device__ __forceinline__ void long_sum(uint32_t (&v)[N], LongSh& sh) {
+    __syncthreads();
+    if (threadIdx.x < N) sh.acc[threadIdx.x] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        const uint32_t w = wave_sum(v[i]);
+        if ((threadIdx.x & 63) == 0 && w) atomicAdd(&sh.acc[i], w);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] = sh.acc[i];
+}
+
+template <bool SPLIT, bool STATS>
+__global__ __launch_bounds__(LONG_THREADS) void place_long_kernel(DbDev db, PlaceParams prm, const uint8_t* __restrict__ bases,
+                                                                  const uint64_t* __restrict__ offsets,
+                                                                  const uint32_t* __restrict__ list,
+                                                                  const uint32_t* __restrict__ list_len,
+                                                                  cls_placement* __restrict__ out, cls_query_stats* __restrict__ stats,
+                                                                  uint32_t* __restrict__ ws, uint64_t ws_stride_words, uint32_t cap,
+                                                                  uint32_t set_size, uint32_t arity_pad) {
+    __shared__ LongSh sh;
+    constexpr uint32_t NT = LONG_THREADS;
+    const uint32_t tid = threadIdx.x, lane = tid & 63;
+    uint32_t* const buf0 = ws + (size_t)blockIdx.x * ws_stride_words;
+    uint32_t* const buf1 = buf0 + (size_t)LONG_STATE_WORDS * cap;
+    uint32_t* const cnt = buf1 + (size_t)LONG_STATE_WORDS * cap;
+    uint32_t* const only = cnt + arity_pad;
+    uint32_t* const set = buf1;               // phase A only: the distinct-hit set lies over the second state buffer
+    uint32_t* const ent = buf0 + 4 * (size_t)cap;  // phase A -> A3: index entry per query k-mer
+    const DNode* __restrict__ nodes = db.nodes;
+    const uint32_t* __restrict__ post = db.postings;
+    const uint4* __restrict__ recs = reinterpret_cast<const uint4*>(db.postings);
+    const uint32_t k = db.k, m_eff = db.m_eff;
+    const bool rm = prm.remove_intersection != 0;
+    const uint32_t n_list = *list_len;
+    for (uint32_t li = blockIdx.x; li < n_list; li += gridDim.x) {
+        __syncthreads();  // the previous read's use of `sh` and of the scratch is over
+        const uint32_t r = list[li];
+        const uint64_t b0 = offsets[r], L64 = offsets[r + 1] - b0;
+        auto put_stats = [&](uint32_t nk_, uint32_t nm, uint32_t nr, uint64_t lp) {
+            if (STATS && stats && tid == 0) {
+                uint64_t* s = reinterpret_cast<uint64_t*>(stats + r);
+                s[0] = (uint64_t)nk_ | ((uint64_t)nm << 32);
+                s[1] = (uint64_t)nr;
+                s[2] = lp;
+            }
+        };
+        auto record = [&](uint32_t status, int32_t one, int32_t rest, uint32_t levels, uint64_t clade) {
+            if (tid == 0) {
+                uint64_t* o = reinterpret_cast<uint64_t*>(out + r);
+                o[0] = (uint64_t)(status & 0xFF) | ((uint64_t)(uint32_t)one << 32);
+                o[1] = (uint64_t)(uint32_t)rest | ((uint64_t)levels << 32);
+                o[2] = clade;
+            }
+        };
+        if (L64 < k) { put_stats(0, 0, 0, 0); record(CLS_ERR_TOO_FEW_KMERS, 0, 0, 0, 0); continue; }
+        const uint64_t nk64 = 2 * (L64 - k + 1);
+        if (nk64 > cap) { put_stats(nk64 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)nk64, 0, 0, 0); record(CLS_ERR_READ_TOO_LONG, 0, 0, 0, 0); continue; }
+        const uint32_t L = (uint32_t)L64, nf = L - k + 1, nk = 2 * nf;
+        // ---- A1. validate (reverse_complement panics on non-ACGT, kmers_map.rs:440) -------------------
+        bool bad = false;
+        for (uint32_t i = tid; i < L; i += NT) {
+            uint8_t c = bases[b0 + i];
+            if (c >= 'a' && c <= 'z') c -= 32;
+            bad |= !(c == 'A' || c == 'C' || c == 'G' || c == 'T');
+        }
+        for (uint32_t i = tid; i < set_size; i += NT) set[i] = SET_EMPTY;
+        if (__syncthreads_or(bad ? 1 : 0)) { put_stats(0, 0, 0, 0); record(CLS_ERR_INVALID_BASE, 0, 0, 0, 0); continue; }
+        // character t of query k-mer j: forward k-mers first, then those of the reverse complement (kmers_map.rs:387-395)
+        auto kmer_char = [&](uint32_t j, uint32_t t) -> uint8_t {
+            const bool rc = j >= nf;
+            uint8_t c = bases[b0 + (rc ? (L - 1 - (j - nf) - t) : (j + t))];
+            if (c >= 'a' && c <= 'z') c -= 32;
+            return rc ? (uint8_t)(c ^ ((c & 2) ? 0x04 : 0x15)) : c;  // A<->T, C<->G
+        };
+        // ---- A2. hash, probe, minimizer-bucket filter, distinct hashes ---------------------------------
+        for (uint32_t j = tid; j < nk; j += NT) {
+            const uint64_t h = murmur3_h1([&](uint32_t t) { return kmer_char(j, t); }, k);
+            const uint64_t mz = murmur3_h1([&](uint32_t t) { return kmer_char(j, t); }, m_eff);
+            bool hit = false;
+            uint64_t loc = 0;
+            uint32_t tidx = 0;
+            uint64_t idx = h & db.table_mask;
+            for (;;) {
+                const Slot sl = db.table[idx];
+                if (sl.loc == SLOT_EMPTY) break;
+                if (sl.hash == h) { hit = true; loc = sl.loc; tidx = (uint32_t)idx; break; }
+                idx = (idx + 1) & db.table_mask;
+            }
+            bool ok = false;
+            if (hit) {
+                const uint64_t bk = db.bucket_key[loc & LOC_BUCKET_MASK];
+                ok = bk == mz;
+                if (!ok) {  // the bucket's key may still be the minimizer of another query k-mer (kmers_map.rs:295-297)
+                    for (uint32_t jj = 0; jj < nk && !ok; ++jj)
+                        ok = murmur3_h1([&](uint32_t t) { return kmer_char(jj, t); }, m_eff) == bk;
+                }
+            }
+            uint32_t e = SET_EMPTY;
+            if (hit && ok) {  // HashSet<u64> of hashes: the first k-mer to claim the entry keeps it
+                uint32_t pos = (tidx * 2654435761u) & (set_size - 1);
+                for (;;) {
+                    const uint32_t old = atomicCAS(&set[pos], SET_EMPTY, tidx);
+                    if (old == SET_EMPTY) { e = (uint32_t)(loc >> LOC_BUCKET_BITS); break; }
+                    if (old == tidx) break;
+                    pos = (pos + 1) & (set_size - 1);
+                }
+            }
+            ent[j] = e;
+        }
+        if (tid == 0) { sh.n_next = 0; sh.acc64 = 0; }
+        __syncthreads();
+        // ---- A3. state of the k-mers that can vote, compacted into buf1 ----------------------------------
+        uint32_t* cur = buf1;
+        uint32_t* nxt = buf0;
+        uint32_t n_m = 0, n_root = 0;
+        {
+            uint64_t leafp = 0;
+            for (uint32_t base = 0; base < nk; base += NT) {
+                const uint32_t j = base + tid;
+                const uint32_t off = j < nk ? ent[j] : SET_EMPTY;
+                const bool is_new = off != SET_EMPTY;
+                bool has_root = false, active = false;
+                uint32_t st[LONG_STATE_WORDS] = {0, 0, 0, 0, 0};
+                if (is_new) {
+                    if constexpr (SPLIT) {
+                        const uint4 hd = recs[off];
+                        if (STATS) leafp += recs[off + 1].x;
+                        has_root = (hd.x & POST_HAS_ROOT) != 0;
+                        active = has_root && (hd.x & POST_LEN_MASK) != 0;
+                        st[0] = hd.z; st[1] = hd.w; st[2] = hd.y;
+                    } else {
+                        const uint32_t w0 = post[off];
+                        if (STATS) leafp += post[off + 1];
+                        has_root = (w0 & POST_HAS_ROOT) != 0;
+                        const uint32_t len = w0 & POST_LEN_MASK;
+                        active = has_root && len != 0;
+                        if (active) {
+                            st[0] = off + POST_HEADER_WORDS; st[1] = st[0] + len;
+                            st[2] = post[st[0]]; st[3] = post[st[1] - 1];
+                            st[4] = (w0 & POST_CLOSED) ? 1u : 0u;
+                        }
+                    }
+                }
+                n_m += is_new ? 1u : 0u;
+                n_root += has_root ? 1u : 0u;
+                const uint32_t p = append_slot(active, &sh.n_next);
+                if (active) {
+#pragma unroll
+                    for (int i = 0; i < (SPLIT ? 3 : LONG_STATE_WORDS); ++i) cur[(size_t)i * cap + p] = st[i];
+                }
+            }
+            if (STATS) {
+                for (int o = 32; o > 0; o >>= 1) leafp += ((uint64_t)__shfl_xor((uint32_t)(leafp >> 32), o) << 32) | __shfl_xor((uint32_t)leafp, o);
+                if (lane == 0 && leafp) atomicAdd(&sh.acc64, (unsigned long long)leafp);
+            }
+            uint32_t v[2] = {n_m, n_root};
+            long_sum<2>(v, sh);
+            n_m = v[0]; n_root = v[1];
+            if (STATS) put_stats(nk, n_m, n_root, (uint64_t)sh.acc64);
+        }
+        uint32_t n_act = sh.n_next;
+        // ---- B. thresholds (as in place_read) ------------------------------------------------------------
+        if (n_m == 0) { record(CLS_UNCLASSIFIABLE_NO_MATCH, 0, 0, 0, 0); continue; }
+        if (n_root == 0) { record(CLS_UNCLASSIFIABLE_NO_ROOT, 0, 0, 0, 0); continue; }
+        if (!(nodes[0].flags & 1u)) { record(CLS_ERR_ROOT_NO_CHILDREN, 0, 0, 0, 0); continue; }
+        {
+            const double expected = round((double)n_m * prm.min_match_coverage);
+            const uint64_t exp_usize = (expected != expected) ? 0ull : (uint64_t)expected;
+            if ((uint64_t)n_root < exp_usize) { record(CLS_UNCLASSIFIABLE_COVERAGE, (int32_t)n_root, 0, 0, 0); continue; }
+        }
+        // ---- C. descent --------------------------------------------------------------------------------------
+        uint32_t prow = 0;
+        int32_t iteration = 0;
+        for (;;) {
+            ++iteration;
+            if (iteration > prm.max_iterations) { record(CLS_ERR_MAX_ITER, 0, 0, (uint32_t)iteration, 0); break; }
+            const uint32_t fc = nodes[prow].first_child, m = nodes[prow].n_nonleaf;  // the non-LEAF children come first
+            __syncthreads();
+            for (uint32_t i = tid; i < m; i += NT) {
+                __hip_atomic_store(&cnt[i], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&only[i], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (tid == 0) { sh.n_pass = 0; sh.n_best = 0; sh.best_diff = 0; sh.n_next = 0; }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+            __syncthreads();
+            const uint32_t last_end = m ? nodes[fc + m - 1].pre + nodes[fc + m - 1].size : 0u;
+            uint32_t U = 0;
+            for (uint32_t j = tid; j < n_act; j += NT) {
+                uint32_t nin = 0, which = 0;
+                if constexpr (SPLIT) {
+                    uint32_t v = cur[j], xx = cur[2 * (size_t)cap + j];
+                    const uint32_t vh = cur[(size_t)cap + j];
+                    while (v < last_end) {  // v lies under exactly one non-LEAF child: the last one starting at or before it
+                        uint32_t lo_ = 0, hi_ = m;
+                        while (hi_ - lo_ > 1) { const uint32_t mid = (lo_ + hi_) >> 1; if (nodes[fc + mid].pre <= v) lo_ = mid; else hi_ = mid; }
+                        const uint32_t c_end = nodes[fc + lo_].pre + nodes[fc + lo_].size;
+                        __hip_atomic_fetch_add(&cnt[lo_], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (nin == 0) which = lo_;
+                        if (nin < 2) ++nin;
+                        if (vh < c_end) break;          // no tip beyond this child
+                        const uint4 t = recs[xx];       // first tip beyond it, and the split of the rest
+                        v = t.z; xx = t.w;
+                    }
+                } else {
+                    const uint32_t lo = cur[j], hi = cur[(size_t)cap + j], vlo = cur[2 * (size_t)cap + j], vhi = cur[3 * (size_t)cap + j];
+                    const bool closed = cur[4 * (size_t)cap + j] != 0;
+                    for (uint32_t ci = 0; ci < m; ++ci) {
+                        const uint32_t c0 = nodes[fc + ci].pre, c1 = c0 + nodes[fc + ci].size;
+                        if (member_of(post, lo, hi, vlo, vhi, closed, c0, c1)) {
+                            __hip_atomic_fetch_add(&cnt[ci], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            if (nin == 0) which = ci;
+                            if (nin < 2) ++nin;
+                        }
+                    }
+                }
+                if (nin == 1) __hip_atomic_fetch_add(&only[which], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                U += nin ? 1u : 0u;
+            }
+            { uint32_t v[1] = {U}; __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent"); long_sum<1>(v, sh); U = v[0]; }
+            // (one, rest), place_sequence.rs:369-395, with |R_c| = |U| - |only_c| and |R_c \ K_c| = |U| - |K_c|
+            for (int pass_no = 0; pass_no < 2; ++pass_no) {
+                for (uint32_t ci = tid; ci < m; ci += NT) {
+                    const uint32_t cn = __hip_atomic_load(&cnt[ci], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (!cn) continue;  // K_c empty: not a candidate (:329)
+                    const uint32_t on = __hip_atomic_load(&only[ci], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const int32_t one = (int32_t)(rm ? on : cn), rest = (int32_t)(rm ? U - cn : U - on);
+                    if (one <= rest) continue;  // :411-417
+                    if (pass_no == 0) { atomicAdd(&sh.n_pass, 1u); atomicMax(&sh.best_diff, one - rest); }
+                    else if (one - rest == sh.best_diff) {
+                        if (atomicAdd(&sh.n_best, 1u) == 0) { sh.best_row = fc + ci; sh.best_one = one; sh.best_rest = rest; }
+                    }
+                }
+                __syncthreads();
+            }
+            const uint32_t n_pass = sh.n_pass, n_best = sh.n_best, best_row = sh.best_row;
+            // ---- PHASE 2 (place_sequence.rs:436-600) ----------------------------------------------------------
+            if (n_pass == 0) {
+                if (iteration == 1) record(CLS_UNCLASSIFIABLE_LEVEL1, 0, 0, 1, 0);
+                else record(CLS_MAX_RESOLUTION, 0, 0, (uint32_t)iteration, nodes[prow].id);
+                break;
+            }
+            if (n_pass > 1 && n_best != 1) { record(CLS_INCONCLUSIVE, (int32_t)n_pass, 0, (uint32_t)iteration, nodes[prow].id); break; }
+            if (nodes[best_row].n_nonleaf == 0) {  // update_introspection_node.rs:13-91
+                record(CLS_IDENTITY_FOUND, sh.best_one, sh.best_rest, (uint32_t)iteration, nodes[best_row].id);
+                break;
+            }
+            // narrow every k-mer to the chosen clade; survivors go to the other buffer
+            const uint32_t c0 = nodes[best_row].pre, c_end = c0 + nodes[best_row].size;
+            for (uint32_t base = 0; base < n_act; base += NT) {
+                const uint32_t j = base + tid;
+                bool keep = false;
+                uint32_t st[LONG_STATE_WORDS] = {0, 0, 0, 0, 0};
+                if (j < n_act) {
+                    if constexpr (SPLIT) {
+                        uint32_t v = cur[j], vh = cur[(size_t)cap + j], xx = cur[2 * (size_t)cap + j];
+                        bool dead = false;
+                        while (v < c0) {  // step past the occupied children before the chosen one
+                            if (vh < c0) { dead = true; break; }
+                            const uint4 t = recs[xx];
+                            v = t.z; xx = t.w;
+                        }
+                        if (!dead && v < c_end && v != c0) {  // a tip strictly below the chosen clade
+                            if (vh >= c_end) { const uint4 t = recs[xx]; vh = t.x; xx = t.y; }  // keep the part inside it
+                            keep = true;
+                            st[0] = v; st[1] = vh; st[2] = xx;
+                        }
+                    } else {
+                        uint32_t lo = cur[j], hi = cur[(size_t)cap + j], vlo = cur[2 * (size_t)cap + j], vhi = cur[3 * (size_t)cap + j];
+                        const uint32_t n0 = c0 + 1;  // the clade itself excluded
+                        if (!(vhi < n0 || vlo >= c_end)) {
+                            keep = true;
+                            if (vlo < n0) { lo = lower_bound_g(post, lo, hi, n0); vlo = post[lo]; if (vlo >= c_end) keep = false; }
+                            if (keep && vhi >= c_end) { hi = lower_bound_g(post, lo, hi, c_end); vhi = post[hi - 1]; }
+                            st[0] = lo; st[1] = hi; st[2] = vlo; st[3] = vhi; st[4] = cur[4 * (size_t)cap + j];
+                        }
+                    }
+                }
+                const uint32_t p = append_slot(keep, &sh.n_next);
+                if (keep) {
+#pragma unroll
+                    for (int i = 0; i < (SPLIT ? 3 : LONG_STATE_WORDS); ++i) nxt[(size_t)i * cap + p] = st[i];
+                }
+            }
+            __syncthreads();
+            n_act = sh.n_next;
+            { uint32_t* t = cur; cur = nxt; nxt = t; }
+            prow = best_row;
+        }
+    }
+}
+
 // ---- read-length classes ----------------------------------------------------------------------
 // One thread per read: reads are binned by their k-mer count into the kernel wide enough for
 // them (class lists in device memory; nothing returns to the host).  Reads no kernel can hold
 // get their record here.
 __global__ void classify_kernel(const uint64_t* __restrict__ offsets, uint32_t n_reads, uint32_t k, uint32_t cap0,
-                                uint32_t cap1, uint32_t cap2, uint32_t* __restrict__ list0, uint32_t* __restrict__ list1,
-                                uint32_t* __restrict__ list2, uint32_t* __restrict__ counts, cls_placement* __restrict__ out,
+                                uint32_t cap1, uint32_t cap2, uint32_t cap3, uint32_t* __restrict__ list0,
+                                uint32_t* __restrict__ list1, uint32_t* __restrict__ list2, uint32_t* __restrict__ list3,
+                                uint32_t* __restrict__ counts, cls_placement* __restrict__ out,
                                 cls_query_stats* __restrict__ stats) {
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
     int cls_id = -1;
@@ -1287,6 +1616,7 @@ __global__ void classify_kernel(const uint64_t* __restrict__ offsets, uint32_t n
         if (nk <= cap0) cls_id = 0;  // includes L < k: the kernel reports CLS_ERR_TOO_FEW_KMERS
         else if (nk <= cap1) cls_id = 1;
         else if (nk <= cap2) cls_id = 2;
+        else if (nk <= cap3) cls_id = 3;  // cap3 = 0: no long-read class in this launch
         else {
             uint64_t* o = reinterpret_cast<uint64_t*>(out + r);
             o[0] = CLS_ERR_READ_TOO_LONG; o[1] = 0; o[2] = 0;
@@ -1298,13 +1628,13 @@ __global__ void classify_kernel(const uint64_t* __restrict__ offsets, uint32_t n
     }
     const uint32_t lane = threadIdx.x & 63;
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
+    for (int c = 0; c < 4; ++c) {
         const uint64_t m = __ballot(cls_id == c);
         if (!m) continue;
         uint32_t base = 0;
         if (lane == 0) base = atomicAdd(&counts[c], (uint32_t)__popcll(m));
         base = __shfl(base, 0);
-        if (cls_id == c) (c == 0 ? list0 : c == 1 ? list1 : list2)[base + __popcll(m & ((1ull << lane) - 1))] = r;
+        if (cls_id == c) (c == 0 ? list0 : c == 1 ? list1 : c == 2 ? list2 : list3)[base + __popcll(m & ((1ull << lane) - 1))] = r;
     }
 }
 
@@ -1370,7 +1700,7 @@ size_t blk_smem(const DbDev& db) {
 }
 }  // namespace
 
-PlacePlan plan_place(const DbDev& db, uint32_t n_reads, uint32_t n_cu, bool stats) {
+PlacePlan plan_place(const DbDev& db, uint32_t n_reads, uint32_t n_cu, bool stats, uint32_t long_cap, uint32_t n_long) {
     PlacePlan p{};
     // persistent-style grids: exactly the blocks that are resident at once (every wave then strides
     // over its class list); CLS_BLOCKS_PER_CU overrides it for tuning experiments
@@ -1393,9 +1723,9 @@ PlacePlan plan_place(const DbDev& db, uint32_t n_reads, uint32_t n_cu, bool stat
     }
     p.grid_blk = std::max<uint32_t>(1, std::min<uint32_t>(n_reads, n_cu));  // 1 workgroup per CU (LDS-bound)
     if (!child_in_lds(db)) child_words = std::max<uint64_t>(child_words, (uint64_t)p.grid_blk * 2 * child_ws_stride(db));
-    // workspace (u32 words): [counts 16][list0 n][list1 n][list2 n][keys_in 2n][keys_out 2n][idx_in n][idx_out n][sort temp][child counters]
+    // workspace (u32 words): [counts 16][list0 n][list1 n][list2 n][list3 n][keys_in 2n][keys_out 2n][idx_in n][idx_out n][sort temp][child counters][long-read slices]
     p.ordered = use_order(db, n_reads);
-    uint64_t w = 16 + 3 * (uint64_t)n_reads;
+    uint64_t w = 16 + 4 * (uint64_t)n_reads;
     w += w & 1;
     if (p.ordered) {
         // 3 workgroups (12 reads) per CU measured best: more reads in flight per XCD evict each other's
@@ -1410,7 +1740,21 @@ PlacePlan plan_place(const DbDev& db, uint32_t n_reads, uint32_t n_cu, bool stat
         w += w & 1;
     }
     p.child_off_words = w;
-    p.ws_bytes = (p.child_off_words + child_words) * 4;
+    w += child_words;
+    w += w & 1;
+    // long-read class: per workgroup two state buffers (the distinct-hit set shares the second) + child counters
+    if (long_cap > MAX_READ_KMERS && n_long) {
+        p.long_cap = long_cap;
+        p.long_set = 1;
+        while (p.long_set < 2 * (uint64_t)long_cap) p.long_set <<= 1;
+        p.long_arity = (std::max(db.max_nonleaf_arity, 1u) + 63) & ~63u;
+        p.long_stride_words = 2 * (uint64_t)LONG_STATE_WORDS * long_cap + 2 * (uint64_t)p.long_arity;
+        const uint64_t fit = std::max<uint64_t>(1, (2ull << 30) / (p.long_stride_words * 4));  // at most 2 GiB of slices
+        p.grid_long = (uint32_t)std::min<uint64_t>({(uint64_t)n_long, (uint64_t)n_cu, fit});
+        p.long_off_words = w;
+        w += p.long_stride_words * p.grid_long;
+    }
+    p.ws_bytes = w * 4;
     return p;
 }
 
@@ -1419,13 +1763,13 @@ hipError_t launch_place(const DbDev& db, const PlaceParams& prm, const PlacePlan
                         uint32_t* d_ws, hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop) {
     if (n_reads == 0) return hipSuccess;
     uint32_t* counts = d_ws;
-    uint32_t* lists[3] = {d_ws + 16, d_ws + 16 + n_reads, d_ws + 16 + 2 * (size_t)n_reads};
+    uint32_t* lists[4] = {d_ws + 16, d_ws + 16 + n_reads, d_ws + 16 + 2 * (size_t)n_reads, d_ws + 16 + 3 * (size_t)n_reads};
     uint32_t* child_ws = (child_ws_stride(db) && !child_in_lds(db)) ? d_ws + plan.child_off_words : nullptr;
     hipError_t e = hipMemsetAsync(counts, 0, 64, stream);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(classify_kernel, dim3((n_reads + 255) / 256), dim3(256), 0, stream, d_offsets, n_reads, db.k,
-                       (uint32_t)(64 * CLS_SLOTS[0]), (uint32_t)(64 * CLS_SLOTS[1]), (uint32_t)(64 * BLK_WAVES * BLK_SLOTS), lists[0],
-                       lists[1], lists[2], counts, d_out, d_stats);
+                       (uint32_t)(64 * CLS_SLOTS[0]), (uint32_t)(64 * CLS_SLOTS[1]), (uint32_t)(64 * BLK_WAVES * BLK_SLOTS), plan.long_cap,
+                       lists[0], lists[1], lists[2], lists[3], counts, d_out, d_stats);
     // CLS_PROFILE_STOP=1|2 truncates the split kernel after the match / state-init phase (timing
     // breakdowns only: the records it then writes are meaningless)
     static const uint32_t profile_stop = [] { const char* e = getenv("CLS_PROFILE_STOP"); return e ? (uint32_t)atoi(e) : 0u; }();
@@ -1514,6 +1858,17 @@ hipError_t launch_place(const DbDev& db, const PlaceParams& prm, const PlacePlan
         else if (binary) { if (st) CLS_LAUNCH_BLK(true, true, false); else CLS_LAUNCH_BLK(false, true, false); }
         else { if (st) CLS_LAUNCH_BLK(true, false, false); else CLS_LAUNCH_BLK(false, false, false); }
 #undef CLS_LAUNCH_BLK
+    }
+    if (plan.grid_long) {  // class 3: reads beyond the register-resident kernels, state in the workspace
+        if (hipGetLastError() != hipSuccess) return hipErrorLaunchFailure;
+        uint32_t* lws = d_ws + plan.long_off_words;
+#define CLS_LAUNCH_LONG(SP, ST)                                                                                                 \
+    hipLaunchKernelGGL((place_long_kernel<SP, ST>), dim3(plan.grid_long), dim3(LONG_THREADS), 0, stream, db, prm, d_bases, d_offsets, \
+                       lists[3], counts + 3, d_out, d_stats, lws, plan.long_stride_words, plan.long_cap, (uint32_t)plan.long_set,  \
+                       plan.long_arity)
+        if (db.format == FMT_SPLIT) { if (st) CLS_LAUNCH_LONG(true, true); else CLS_LAUNCH_LONG(true, false); }
+        else { if (st) CLS_LAUNCH_LONG(false, true); else CLS_LAUNCH_LONG(false, false); }
+#undef CLS_LAUNCH_LONG
     }
     return hipGetLastError();
 }

@@ -21,7 +21,8 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libclsplace.so")
 _LIB = None
 
 EXPORTS = [
-    "cls_device_count", "cls_db_create", "cls_db_validate", "cls_db_destroy", "cls_db_info_get", "cls_db_kernel_time", "cls_place_batch",
+    "cls_device_count", "cls_db_create", "cls_db_validate", "cls_db_destroy", "cls_db_info_get", "cls_db_kernel_time",
+    "cls_db_set_max_read_len", "cls_place_batch",
     "cls_place_batch_device", "cls_place_batch_stats", "cls_fasta_parse", "cls_fasta_free", "cls_last_error",
     "cls_version",
 ]
@@ -60,6 +61,8 @@ def lib():
         L.cls_db_info_get.restype = i32
         L.cls_db_kernel_time.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_uint64), i32]
         L.cls_db_kernel_time.restype = i32
+        L.cls_db_set_max_read_len.argtypes = [vp, C.c_uint64]
+        L.cls_db_set_max_read_len.restype = i32
         L.cls_place_batch.argtypes = [vp, vp, vp, u32, C.POINTER(_abi.Params), vp]
         L.cls_place_batch.restype = i32
         L.cls_place_batch_stats.argtypes = [vp, vp, vp, u32, C.POINTER(_abi.Params), vp, vp]
@@ -191,6 +194,11 @@ class PlacementDb:
         ms, cnt = C.c_double(0), C.c_uint64(0)
         _check(lib().cls_db_kernel_time(self._h, C.byref(ms), C.byref(cnt), 1 if reset else 0))
         return ms.value, cnt.value
+
+    def set_max_read_len(self, n_bases: int) -> None:
+        """Longest read place_batch_device() provisions for (cls_db_set_max_read_len)."""
+        _check(lib().cls_db_set_max_read_len(self._h, n_bases))
+        _check(lib().cls_db_info_get(self._h, C.byref(self.info)))
 
     def place_batch_device(self, d_bases: int, d_offsets: int, n: int, d_out: int, params: Optional[_abi.Params] = None,
                            d_stats: int = 0, stream: int = 0) -> None:

@@ -113,7 +113,9 @@ typedef struct cls_params {
  * CLS_ERR_MAX_ITER               Err("The maximum number of iterations has been reached.", UCPLACE0010) :295-301
  * CLS_ERR_ROOT_NO_CHILDREN       Err("The root node does not have children. This is unexpected.") :199-206
  * CLS_ERR_INVALID_BASE           the reference panics (kmers_map.rs:440); reported per read instead
- * CLS_ERR_READ_TOO_LONG          read exceeds the engine's per-read k-mer capacity (cls_db_info.max_read_kmers)
+ * CLS_ERR_READ_TOO_LONG          device-buffer entry only: the read is longer than the handle provisions for
+ *                                (cls_db_set_max_read_len; cls_db_info.max_read_kmers); the host-buffer entries size
+ *                                themselves by the batch and place reads of up to 2^25 bases
  */
 enum {
     CLS_UNCLASSIFIABLE_NO_MATCH = 0,
@@ -164,7 +166,7 @@ typedef struct cls_db_info {
     uint64_t table_slots;
     uint64_t postings_words;
     uint64_t hbm_bytes;        /* device bytes held by the handle                */
-    uint32_t max_read_kmers;   /* per-read k-mer capacity of the kernels         */
+    uint32_t max_read_kmers;   /* per-read k-mer capacity of the device-buffer entry */
     int32_t device;
     uint32_t format;           /* 0: sorted lists (some node set is not closed under `parent`); 1: split-tree records */
     uint32_t binary_tree;      /* 1: every clade has zero or two children        */
@@ -200,6 +202,11 @@ int cls_place_batch(cls_db* db, const char* bases, const uint64_t* offsets, uint
  * stream).  `d_stats` may be NULL.  This is the entry bench.py times. */
 int cls_place_batch_device(cls_db* db, const void* d_bases, const void* d_offsets, uint32_t n,
                            const cls_params* params, void* d_out, void* d_stats, void* hip_stream);
+
+/* Longest read (bases) cls_place_batch_device() provisions scratch for (default 16384; the lengths of a
+ * device-resident batch are not known to the host).  Reads with more than 8192 k-mers keep their per-k-mer
+ * state in the workspace: 80 bytes per base and resident workgroup.  At most 2^25. */
+int cls_db_set_max_read_len(cls_db* db, uint64_t n_bases);
 
 /* Device time of the DOMINANT placement kernel (the per-read placement kernel of the
  * 320-k-mer class), accumulated over every cls_place_batch_device() launch on this

@@ -71,14 +71,69 @@ def test_ragged_and_edge_reads():
     assert (got2["status"][victims] == _abi.ERR_INVALID_BASE).all()
 
 
+def _device_place(db, bases, offsets, want_stats=True):
+    """cls_place_batch_device on torch-owned HBM buffers."""
+    import torch
+
+    dev = torch.device("cuda:0")
+    n = len(offsets) - 1
+    d_b = torch.from_numpy(bases if len(bases) else np.zeros(1, np.uint8)).to(dev)
+    d_o = torch.from_numpy(offsets.astype(np.int64)).to(dev)
+    d_out = torch.zeros(n * 24, dtype=torch.uint8, device=dev)
+    d_st = torch.zeros(n * 24, dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
+    db.place_batch_device(d_b.data_ptr(), d_o.data_ptr(), n, d_out.data_ptr(), None, d_st.data_ptr() if want_stats else 0, 0)
+    torch.cuda.synchronize()
+    return d_out.cpu().numpy().view(_abi.PLACEMENT_DTYPE), d_st.cpu().numpy().view(_abi.STATS_DTYPE)
+
+
 def test_read_too_long_reported():
-    s = SynthDb(30, 5000, 9, 4)
-    bases, offsets, _ = s.reads(6, 4800)
+    """The device-buffer entry provisions for the handle's max_read_len; beyond it reads are refused, not misplaced."""
+    s = SynthDb(30, 21000, 9, 4)
+    bases, offsets, _ = s.reads(6, 20000)
     with engine.PlacementDb(s.flat, device=0) as db:
-        got, st = db.place_batch(bases, offsets, want_stats=True)
-        assert 2 * (4800 - 9 + 1) > db.info.max_read_kmers
-    assert (got["status"] == _abi.ERR_READ_TOO_LONG).all()
-    assert (st["n_query_kmers"] == 2 * (4800 - 9 + 1)).all()
+        assert 2 * (20000 - 9 + 1) > db.info.max_read_kmers
+        got, st = _device_place(db, bases, offsets)
+        assert (got["status"] == _abi.ERR_READ_TOO_LONG).all()
+        assert (st["n_query_kmers"] == 2 * (20000 - 9 + 1)).all()
+        db.set_max_read_len(20000)
+        assert db.info.max_read_kmers == 40000
+        got2, st2 = _device_place(db, bases, offsets)
+        host, hst = db.place_batch(bases, offsets, want_stats=True)  # sizes itself by the batch
+    want, wst = op.OraclePort(s.flat).place_batch(bases, offsets, op.make_params(), threads=8, want_stats=True)
+    assert len(records_equal(got2, want)) == 0 and len(records_equal(host, want)) == 0
+    assert len(stats_equal(st2, wst)) == 0 and len(stats_equal(hst, wst)) == 0
+
+
+@pytest.mark.parametrize("k,collapse,drop,deep", [(15, 0.0, 0.0, 0), (12, 0.4, 0.0, 0), (11, 0.3, 0.2, 0), (15, 0.0, 0.0, 1), (20, 0.5, 0.0, 1)])
+def test_long_reads_workspace_kernel(k, collapse, drop, deep):
+    """Reads of 4.2..11 kb (BASELINE config 5 has 10 kb reads): more k-mers than the register-resident kernels
+    hold, so the per-k-mer state lives in the workspace; every index format, bushy and ladder-like trees."""
+    s = SynthDb(90, 11500, k, 4, collapse_prob=collapse, deep=deep)
+    flat = drop_random_nodes(s.flat, drop, seed=8) if drop else s.flat
+    rng = np.random.default_rng(33)
+    bases, offsets = ragged_reads(rng, s, 40, 4200, 11000, lower_frac=0.05)
+    got = None
+    for kw in (dict(), dict(remove_intersection=True, max_iterations=9)):
+        got = _check(flat, bases, offsets, kw, threads=16)
+    assert (got["status"] != _abi.ERR_READ_TOO_LONG).all()
+
+
+def test_long_and_short_reads_in_one_batch():
+    """One batch through all four kernels (320 / 1024 / 8192 k-mers and the workspace kernel), an invalid base
+    in a long read, and a long read of random bases."""
+    s = SynthDb(120, 9000, 13, 4, collapse_prob=0.2)
+    rng = np.random.default_rng(5)
+    parts = [ragged_reads(rng, s, 150, 0, 400), ragged_reads(rng, s, 20, 600, 4000), ragged_reads(rng, s, 12, 4300, 8800, frac_random=0.2)]
+    bases = np.concatenate([p[0] for p in parts])
+    offsets = np.zeros(1, dtype=np.uint64)
+    for b, o in parts:
+        offsets = np.concatenate([offsets, o[1:] + offsets[-1]])
+    bases = bases.copy()
+    o = offsets.astype(np.int64)
+    bases[o[-2] + 3000] = ord("N")  # inside the last read, a long one
+    got = _check(s.flat, bases, offsets, {}, threads=16)
+    assert got["status"][-1] == _abi.ERR_INVALID_BASE
 
 
 @pytest.mark.parametrize("k,collapse,drop", [(12, 0.0, 0.0), (35, 0.0, 0.0), (11, 0.4, 0.0), (10, 0.3, 0.2), (16, 0.0, 0.15)])
