@@ -264,7 +264,7 @@ int encode_db(const cls_db_desc* d, EncodedDb& E, std::string& err) {
                 uint32_t* h = &recs[base * 4];
                 h[0] = w[0];
                 h[1] = root ? at(root) : 0;
-                h[2] = n ? tip[0] : 0;
+                h[2] = n ? tip[0] : 0xFFFFFFFFu;  // no tip below the root: the "inactive" state {MAX, 0}
                 h[3] = n ? tip[n - 1] : 0;
                 h[4] = w[1];  // n_leaf_ids (statistics)
                 h[5] = (uint32_t)d_kmer_hash[j];
@@ -304,11 +304,11 @@ int encode_db(const cls_db_desc* d, EncodedDb& E, std::string& err) {
         E.table[i] = Slot{h, (off << LOC_BUCKET_BITS) | bucket_of[j]};
     }
     // ---- 6. direct table for small k -----------------------------------------------------
-    if (E.format == FMT_SPLIT && E.strictly_binary && d->k_size <= DIRECT_MAX_K) {
+    if (E.format == FMT_SPLIT && E.strictly_binary && d->k_size <= DIRECT_MAX_K && N < DIRECT_TIP_MASK) {
         const uint32_t K = (uint32_t)d->k_size, M = (uint32_t)std::min<uint64_t>(d->m_size, d->k_size);
         const uint64_t n_codes = 1ULL << (2 * K);
-        E.direct.assign(2 * n_codes, 0);  // {record offset, locality meta} per code
-        for (uint64_t c = 0; c < n_codes; ++c) E.direct[2 * c + 1] = 0xFFFFFFFFu;
+        E.direct.assign(4 * n_codes, 0);  // {record offset, root split, first tip | bit length << 27, last tip | has_root << 31}
+        for (uint64_t c = 0; c < n_codes; ++c) E.direct[4 * c + 2] = 0xFFFFFFFFu;
         std::atomic<bool> foreign{false};
         std::atomic<uint64_t> found{0};
         parallel_chunks(n_codes, nt, [&](unsigned, uint64_t lo, uint64_t hi) {
@@ -326,8 +326,12 @@ int encode_db(const cls_db_desc* d, EncodedDb& E, std::string& err) {
                     const uint32_t n_tips = E.postings[(size_t)off * 4] & POST_LEN_MASK;
                     uint32_t lg = 0;
                     while (lg < 31 && (1u << lg) <= n_tips) ++lg;  // bit length: small = specific k-mer
-                    E.direct[2 * code] = off;
-                    E.direct[2 * code + 1] = n_tips ? ((lg << DIRECT_TIP_BITS) | (E.postings[(size_t)off * 4 + 2] & DIRECT_TIP_MASK)) : 0xFFFFFFFFu;
+                    const uint32_t* hd = &E.postings[(size_t)off * 4];  // {n | flags, root split, first tip, last tip}
+                    uint32_t* e = &E.direct[4 * code];
+                    e[0] = off;
+                    e[1] = hd[1];
+                    e[2] = n_tips ? ((lg << DIRECT_TIP_BITS) | hd[2]) : 0xFFFFFFFFu;
+                    e[3] = (n_tips ? hd[3] : 0u) | ((hd[0] & POST_HAS_ROOT) ? 0x80000000u : 0u);
                     ++cnt;
                     break;
                 }

@@ -69,15 +69,18 @@ constexpr uint32_t POST_HEADER_WORDS = 2;
 constexpr uint32_t SPLIT_HEADER_RECS = 2;
 constexpr uint32_t SPLIT_FIRST_REC = 2;
 
-// ---- direct k-mer table (k <= DIRECT_MAX_K, FMT_SPLIT only) ----------------------
+// ---- direct k-mer table (k <= DIRECT_MAX_K, FMT_SPLIT, binary tree) ------------------------
 // For small k every possible k-mer is enumerated once at cls_db_create(): its 2-bit
-// code (A=0 C=1 T=2 G=3 = (ascii >> 1) & 3, first base in the low bits) indexes a
-// u32 table holding the record offset of its header (0 = not in the index), so the
-// query side needs neither MurmurHash nor a probe loop.  Only built when every
-// index entry sits in the minimizer bucket of its own prefix (true for every
-// `cls build-db` output), which makes the bucket filter of kmers_map.rs:295-297 a no-op.
-// Entry = {record offset (0 = absent), meta}; meta = bit_length(n_tips) << 27 | first tip
-// (0xFFFFFFFF if absent) feeds the locality ordering of cls_kernels.hip (order_key_kernel).
+// code (A=0 C=1 T=2 G=3 = (ascii >> 1) & 3, first base in the low bits) indexes a table
+// of 16-byte entries that hold the k-mer's whole initial descent state, so the query
+// side needs neither MurmurHash, nor a probe loop, nor the header record:
+//   {record offset of the header (0 = not in the index), root split,
+//    first tip | bit_length(n_tips) << 27   (0xFFFFFFFF: absent / no tip below the root),
+//    last tip  | has_root << 31}
+// The bit length feeds the locality ordering of cls_kernels.hip (order_key_kernel).
+// Only built when every index entry sits in the minimizer bucket of its own prefix (true
+// for every `cls build-db` output), which makes the bucket filter of kmers_map.rs:295-297
+// a no-op, and when pre-order indices fit DIRECT_TIP_BITS.
 constexpr uint32_t DIRECT_MAX_K = 15;
 constexpr uint32_t DIRECT_TIP_BITS = 27;
 constexpr uint32_t DIRECT_TIP_MASK = (1u << DIRECT_TIP_BITS) - 1;
@@ -96,7 +99,7 @@ struct DbDev {
     const Slot* table;
     const uint32_t* postings;   // FMT_LIST: u32 words; FMT_SPLIT: TipRec records (16-byte units)
     const uint64_t* bucket_key;
-    const uint32_t* direct;     // 4^k pairs {offset, meta} or nullptr
+    const uint32_t* direct;     // 4^k entries of 4 words (above) or nullptr
     uint64_t table_mask;
     uint32_t n_nodes;
     uint32_t n_buckets;

@@ -941,11 +941,12 @@ struct FastCtx {
 };
 
 // Front of the fast path, shared with order_key_kernel: the read -> LDS (upper-cased, validated),
-// 2 bits per base, then per query k-mer its 2-bit code and the direct-table entry.
+// 2 bits per base, then per query k-mer its 2-bit code and the direct-table entry
+// {header offset, root split, first tip | bit length << 27, last tip | has_root << 31}.
 // Returns false if the read holds a character other than ACGT.
 template <int SLOTS, int SET_BITS, bool ADDR32>
 __device__ __forceinline__ bool fast_front(const DbDev& db, const FastCtx& cx, const uint8_t* __restrict__ bases, uint64_t b0,
-                                           uint32_t L, uint32_t nf, uint32_t nk, uint32_t (&off)[SLOTS], uint32_t (&meta)[SLOTS],
+                                           uint32_t L, uint32_t nf, uint32_t nk, uint4 (&ent)[SLOTS],
                                            uint32_t sample_shift = 32, bool canonical = false) {
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t k = db.k;
@@ -996,9 +997,8 @@ __device__ __forceinline__ bool fast_front(const DbDev& db, const FastCtx& cx, c
         // sample_shift < 32: look up only the k-mers whose scrambled code has its top bits clear (a content-
         // based sample, the same k-mers in every read that contains them); 32 = all
         const bool take = valid && (sample_shift >= 32 || ((code * 0x9E3779B1u) >> sample_shift) == 0);
-        const uint2 e = ldx<uint2, ADDR32>(direct, take ? code : 0u);
-        off[s] = take ? e.x : 0u;
-        meta[s] = take ? e.y : 0xFFFFFFFFu;
+        const uint4 e = ldx<uint4, ADDR32>(direct, take ? code : 0u);
+        ent[s] = take ? e : uint4{0u, 0u, 0xFFFFFFFFu, 0u};
     }
     return true;
 }
@@ -1022,8 +1022,8 @@ __device__ __forceinline__ void place_read_fast(const DbDev& db, const PlacePara
     if (L64 < k) { put_stats(0, 0, 0, 0); write_record(out, r, CLS_ERR_TOO_FEW_KMERS, 0, 0, 0, 0); return; }
     const uint32_t L = (uint32_t)L64, nf = L - k + 1, nk = 2 * nf;  // nk <= 64*SLOTS by classification
     // ---- A1/A2. load + validate + 2-bit pack; per k-mer: code -> direct table ----------------------
-    uint32_t off[SLOTS], meta[SLOTS];
-    if (!fast_front<SLOTS, SET_BITS, ADDR32>(db, cx, bases, b0, L, nf, nk, off, meta)) {
+    uint4 ent[SLOTS];
+    if (!fast_front<SLOTS, SET_BITS, ADDR32>(db, cx, bases, b0, L, nf, nk, ent)) {
         put_stats(0, 0, 0, 0);
         write_record(out, r, CLS_ERR_INVALID_BASE, 0, 0, 0, 0);
         return;
@@ -1032,31 +1032,30 @@ __device__ __forceinline__ void place_read_fast(const DbDev& db, const PlacePara
     // distinct hashes: the FIRST k-mer that reaches an entry keeps it (HashSet<u64> semantics)
 #pragma unroll
     for (int s = 0; s < SLOTS; ++s) {
-        if (off[s] != 0) {
-            const uint32_t key = off[s];
+        if (ent[s].x != 0) {
+            const uint32_t key = ent[s].x;
             uint32_t pos = (key * 2654435761u) >> (32 - SET_BITS);
 #pragma unroll 1
             for (;;) {
                 const uint32_t old = atomicCAS(&cx.set[pos], SET_EMPTY, key);
                 if (old == SET_EMPTY) break;
-                if (old == key) { off[s] = 0; break; }
+                if (old == key) { ent[s] = uint4{0u, 0u, 0xFFFFFFFFu, 0u}; break; }
                 pos = (pos + 1) & ((1u << SET_BITS) - 1);
             }
         }
     }
-    if (profile_stop == 1) { write_record(out, r, 0xFE, (int32_t)(off[0] + off[SLOTS - 1]), 0, 0, 0); return; }  // profiling aid
-    // ---- A3. state from the headers (record 0 = the dummy "inactive" header) --------------------------
+    if (profile_stop == 1) { write_record(out, r, 0xFE, (int32_t)(ent[0].x + ent[SLOTS - 1].x), 0, 0, 0); return; }  // profiling aid
+    // ---- A3. the descent state comes with the table entry: no header read -----------------------------
     uint32_t vlo[SLOTS], vhi[SLOTS], x[SLOTS];
     uint32_t cnt = 0;  // |M| in bits 0..15, |M_root| in bits 16..31 (per lane, then summed)
     uint64_t leafp = 0;
 #pragma unroll
     for (int s = 0; s < SLOTS; ++s) {
-        const uint4 hd = ldx<uint4, ADDR32>(recs, off[s]);  // {n | flags, root split, first tip, last tip}
-        if (STATS) leafp += ldx<uint4, ADDR32>(recs, off[s] + 1).x;
-        vlo[s] = hd.z;
-        vhi[s] = hd.w;
-        x[s] = hd.y;
-        cnt += (off[s] != 0 ? 1u : 0u) + ((hd.x >> 31) << 16);
+        if (STATS) leafp += ldx<uint4, ADDR32>(recs, ent[s].x + 1).x;  // record 1 (the dummy's second half) holds 0
+        vlo[s] = ent[s].z & DIRECT_TIP_MASK;  // absent / tip-less: the largest value, above every interval bound
+        vhi[s] = ent[s].w & 0x7FFFFFFFu;
+        x[s] = ent[s].y;
+        cnt += (ent[s].x != 0 ? 1u : 0u) + ((ent[s].w >> 31) << 16);
     }
     cnt = wave_sum(cnt);
     const uint32_t n_m = cnt & 0xFFFFu, n_root = cnt >> 16;
@@ -1225,10 +1224,10 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void order_key_kernel(DbDev d
         uint64_t key = ~0ull;
         if (L64 >= db.k && 2 * (L64 - db.k + 1) <= (uint64_t)(64 * SLOTS)) {
             const uint32_t L = (uint32_t)L64, nf = L - db.k + 1, nk = 2 * nf;
-            uint32_t off[SLOTS], meta[SLOTS];
+            uint4 ent[SLOTS];
             // one lookup per window, of the smaller of the k-mer and its reverse complement: an index built from
             // both strands files the two under the same leaves, and the key then does not depend on the strand read
-            if (fast_front<SLOTS, 0, ADDR32>(db, cx, bases, b0, L, nf, fwd_only ? nf : nk, off, meta, sample_shift, fwd_only != 0)) {
+            if (fast_front<SLOTS, 0, ADDR32>(db, cx, bases, b0, L, nf, fwd_only ? nf : nk, ent, sample_shift, fwd_only != 0)) {
                 // candidates: k-mers present in the index that are specific to a small clade (few tips);
                 // the tip bound is widened until a handful qualify (finally: every k-mer present)
                 uint32_t cand = 0, n_cand = 0;
@@ -1237,7 +1236,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void order_key_kernel(DbDev d
                     cand = 0; n_cand = 0;
 #pragma unroll
                     for (int s = 0; s < SLOTS; ++s) {
-                        const bool c = off[s] != 0 && (meta[s] >> DIRECT_TIP_BITS) <= lg_max;
+                        const bool c = ent[s].x != 0 && (ent[s].z >> DIRECT_TIP_BITS) <= lg_max;
                         cand |= (c ? 1u : 0u) << s;
                         n_cand += popc64(__ballot(c));
                     }
@@ -1250,7 +1249,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void order_key_kernel(DbDev d
                         uint32_t c0 = 0;
 #pragma unroll
                         for (int s = 0; s < SLOTS; ++s) {
-                            const uint32_t t = meta[s] & DIRECT_TIP_MASK;
+                            const uint32_t t = ent[s].z & DIRECT_TIP_MASK;
                             const bool z = ((cand >> s) & 1u) && ((t ^ prefix) >> (bit + 1)) == 0 && !((t >> bit) & 1u);
                             c0 += popc64(__ballot(z));
                         }
@@ -1260,7 +1259,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void order_key_kernel(DbDev d
                     // reads that share most of their specific k-mers share it)
                     uint32_t mh = 0xFFFFFFFFu;
 #pragma unroll
-                    for (int s = 0; s < SLOTS; ++s) if ((cand >> s) & 1u) mh = off[s] < mh ? off[s] : mh;
+                    for (int s = 0; s < SLOTS; ++s) if ((cand >> s) & 1u) mh = ent[s].x < mh ? ent[s].x : mh;
                     for (int o = 32; o > 0; o >>= 1) { const uint32_t other = __shfl_xor(mh, o); mh = other < mh ? other : mh; }
                     key = ((uint64_t)(prefix >> block_shift) << 32) | mh;
                 }

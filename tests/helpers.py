@@ -58,6 +58,25 @@ def drop_random_nodes(flat: FlatDb, frac: float, seed: int, keep_root_frac: floa
                   kmer_node_off=new_off, node_ids=new_ids)
 
 
+def truncate_random_sets(flat: FlatDb, frac: float, seed: int) -> FlatDb:
+    """Node sets that stay closed under `parent` but hold nothing below the root: a random fraction of the k-mers
+    keeps only {root}, another one the empty set (an index file may say so; `cls build-db` never does)."""
+    rng = np.random.default_rng(seed)
+    root_id = int(flat.nodes[0]["id"])
+    off = flat.kmer_node_off.astype(np.int64)
+    nk = len(off) - 1
+    u = rng.random(nk)
+    mode = np.where(u < frac, 1, np.where(u < 2 * frac, 2, 0))  # 1: {root}, 2: {}
+    owner = np.repeat(np.arange(nk), np.diff(off))
+    is_root = flat.node_ids == root_id
+    keep = (mode[owner] == 0) | ((mode[owner] == 1) & is_root)
+    new_ids = flat.node_ids[keep]
+    csum = np.concatenate([[0], np.cumsum(keep)])
+    return FlatDb(nodes=flat.nodes.copy(), k_size=flat.k_size, m_size=flat.m_size, bucket_key=flat.bucket_key.copy(),
+                  bucket_kmer_off=flat.bucket_kmer_off.copy(), kmer_hash=flat.kmer_hash.copy(),
+                  kmer_node_off=csum[off].astype(np.uint64), node_ids=new_ids)
+
+
 def ragged_reads(rng, synth, n, min_len, max_len, err=0.02, frac_random=0.05, lower_frac=0.1):
     """Reads of varying length (incl. shorter than k and empty), some lower-case."""
     lens = rng.integers(min_len, max_len + 1, size=n)

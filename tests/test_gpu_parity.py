@@ -5,7 +5,8 @@ import pytest
 from classeq2_amd import _abi, engine
 from classeq2_amd.synth import SynthDb
 from oracle import oracle_port as op
-from tests.helpers import ODD_PARAM_SETS, PARAM_SETS, describe, drop_random_nodes, ragged_reads, records_equal, stats_equal
+from tests.helpers import (ODD_PARAM_SETS, PARAM_SETS, describe, drop_random_nodes, ragged_reads, records_equal, stats_equal,
+                           truncate_random_sets)
 
 pytestmark = pytest.mark.gpu
 
@@ -52,6 +53,19 @@ def test_non_closed_node_sets(frac):
     bases, offsets, _ = s.reads(1500, 90, frac_random=0.05, err=0.02)
     for kw in PARAM_SETS[:3]:
         _check(flat, bases, offsets, kw)
+
+
+@pytest.mark.parametrize("k,collapse", [(9, 0.0), (12, 0.0), (10, 0.4), (17, 0.0)])
+def test_sets_with_nothing_below_the_root(k, collapse):
+    """k-mers whose node set is {root} or {} count towards |M| / |M_root| but never vote; every kernel
+    family (direct-table fast path for k <= 15 on binary trees, split-tree walk, hash probe)."""
+    s = SynthDb(70, 300, k, 4, collapse_prob=collapse)
+    flat = truncate_random_sets(s.flat, 0.15, seed=4)
+    bases, offsets, _ = s.reads(1200, 110, frac_random=0.05, err=0.02)
+    for kw in (dict(), dict(min_match_coverage=1.0), dict(remove_intersection=True)):
+        _check(flat, bases, offsets, kw)
+    with engine.PlacementDb(flat, device=0) as db:
+        assert db.info.format == 1 and db.info.direct_table == (1 if k <= 15 and collapse == 0.0 else 0)
 
 
 def test_ragged_and_edge_reads():

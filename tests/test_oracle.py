@@ -62,6 +62,22 @@ def test_port_matches_literal(case):
         assert len(records_equal(got, want)) == 0, kw
 
 
+def test_port_matches_literal_sets_with_nothing_below_the_root():
+    """Node sets {root} and {}: counted in |M| (and |M_root|), never a vote."""
+    from tests.helpers import truncate_random_sets
+
+    s = SynthDb(60, 300, 9, 4)
+    flat = truncate_random_sets(s.flat, 0.15, seed=4)
+    tree = op.flat_to_literal(flat)
+    port = op.OraclePort(flat)
+    bases, offsets, _ = s.reads(150, 110, frac_random=0.05, err=0.02)
+    for kw in (dict(), dict(min_match_coverage=1.0)):
+        want = op.literal_place_batch(tree, bases, offsets, **kw)
+        got, st = port.place_batch(bases, offsets, op.make_params(**kw), threads=2, want_stats=True)
+        assert len(records_equal(got, want)) == 0, kw
+    assert (st["n_matched"] > st["n_with_root"]).any()
+
+
 def test_port_matches_literal_non_closed_and_ragged():
     s = SynthDb(60, 300, 8, 4, collapse_prob=0.3)
     flat = drop_random_nodes(s.flat, 0.2, seed=3)
