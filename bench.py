@@ -193,7 +193,7 @@ def main():
                             f"k={cfg['k_size']}, m={cfg['m_size']} (seeds tree=1 refseq=2 reads=3)",
                 "reads_per_gpu": per_gpu,
                 "parallelism": f"reads sharded x{world}, index replicated, 1 gather/step" if world > 1 else "single GPU",
-                "index": {"n_nodes": int(db.info.n_nodes), "n_kmers": int(db.info.n_kmers), "max_depth": int(db.info.max_depth),
+                "index": {"n_nodes": int(db.info.n_nodes), "n_kmers": int(db.info.n_kmers), "n_tip_sets": int(db.info.n_tip_sets), "max_depth": int(db.info.max_depth),
                           "hbm_bytes": int(db.info.hbm_bytes)},
                 "status_counts": {_abi.STATUS_NAMES[i]: int(c) for i, c in enumerate(counts) if c},
                 "mean_levels": float(ref_out["levels"].mean()),

@@ -120,7 +120,7 @@ class DbInfo(C.Structure):
         ("format", C.c_uint32),
         ("binary_tree", C.c_uint32),
         ("direct_table", C.c_uint32),
-        ("pad_", C.c_uint32),
+        ("n_tip_sets", C.c_uint32),
     ]
 
 

@@ -168,6 +168,7 @@ extern "C" int cls_db_create(const cls_db_desc* d, int device, cls_db** out) {
         i.format = E.format;
         i.binary_tree = E.strictly_binary ? 1u : 0u;
         i.direct_table = E.direct.empty() ? 0u : 1u;
+        i.n_tip_sets = (uint32_t)E.n_sets;
         *out = db;
         return CLS_OK;
     } catch (const std::bad_alloc&) {

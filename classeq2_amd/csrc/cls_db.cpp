@@ -6,6 +6,7 @@
 #include "cls_murmur.h"
 
 #include <stdlib.h>
+#include <string.h>
 
 #include <algorithm>
 #include <atomic>
@@ -25,6 +26,27 @@ void parallel_chunks(uint64_t n, unsigned n_threads, const std::function<void(un
     for (unsigned t = 0; t < n_threads; ++t)
         th.emplace_back([=, &fn] { fn(t, n * t / n_threads, n * (t + 1) / n_threads); });
     for (auto& x : th) x.join();
+}
+
+// sort `v` with `cmp` on up to n_threads threads: sorted runs, then pairwise merges
+template <class T, class Cmp>
+void parallel_sort(std::vector<T>& v, unsigned n_threads, Cmp cmp) {
+    const uint64_t n = v.size();
+    unsigned parts = 1;
+    while (parts * 2 <= n_threads && n / (parts * 2) >= 65536) parts *= 2;
+    if (parts == 1) { std::sort(v.begin(), v.end(), cmp); return; }
+    auto bound = [&](unsigned i) { return v.begin() + (ptrdiff_t)(n * i / parts); };
+    {
+        std::vector<std::thread> th;
+        for (unsigned i = 0; i < parts; ++i) th.emplace_back([&, i] { std::sort(bound(i), bound(i + 1), cmp); });
+        for (auto& x : th) x.join();
+    }
+    for (unsigned width = 1; width < parts; width *= 2) {
+        std::vector<std::thread> th;
+        for (unsigned i = 0; i + width < parts; i += 2 * width)
+            th.emplace_back([&, i, width] { std::inplace_merge(bound(i), bound(i + width), bound(std::min(parts, i + 2 * width)), cmp); });
+        for (auto& x : th) x.join();
+    }
 }
 
 }  // namespace
@@ -208,23 +230,68 @@ int encode_db(const cls_db_desc* d, EncodedDb& E, std::string& err) {
     // CLS_FORCE_LIST=1 keeps the sorted-list form (A/B experiments only)
     E.format = (n_closed.load() == NK && getenv("CLS_FORCE_LIST") == nullptr) ? FMT_SPLIT : FMT_LIST;
     if (E.format == FMT_SPLIT) {
-        // per k-mer: 2 header records + (n-1) split nodes + (n == 1 ? 0 : 0) ... see cls_device.h
-        std::vector<uint64_t> rec_off(NK + 1, 0);
-        rec_off[0] = SPLIT_FIRST_REC;  // records 0/1: the dummy "no k-mer" header
-        for (uint64_t j = 0; j < NK; ++j) {
-            const uint32_t n = E.postings[kmer_off[j]] & POST_LEN_MASK;
-            rec_off[j + 1] = rec_off[j] + SPLIT_HEADER_RECS + (n ? n - 1 : 0);
-        }
-        if (rec_off[NK] >= (1ULL << 32)) { err = "split-tree postings exceed 2^32 records"; return CLS_E_BAD_DB; }
-        std::vector<uint32_t> recs((rec_off[NK] + 1) * 4, 0);
-        recs[2] = 0xFFFFFFFFu;  // dummy header {0, 0, first tip = MAX, last tip = 0}: decodes to "inactive"
+        // k-mers with the SAME tip list (neighbouring k-mers of a conserved region) share one split tree:
+        // group them exactly (signature first, then the lists themselves).
+        std::vector<uint64_t> sig(NK);
         parallel_chunks(NK, nt, [&](unsigned, uint64_t lo, uint64_t hi) {
-            std::vector<uint32_t> d, stk, L, R, pos, span_lo, span_hi;
             for (uint64_t j = lo; j < hi; ++j) {
                 const uint32_t* w = &E.postings[kmer_off[j]];
                 const uint32_t n = w[0] & POST_LEN_MASK;
-                const uint32_t* tip = w + POST_HEADER_WORDS;
-                const uint64_t base = rec_off[j];  // 2 header records, then the split nodes
+                uint64_t h = 0x9E3779B97F4A7C15ull ^ n;
+                for (uint32_t i = 0; i < n; ++i) h = fmix64(h ^ w[POST_HEADER_WORDS + i]) + 0x632BE59BD9B4E019ull;
+                sig[j] = h;
+            }
+        });
+        std::vector<uint32_t> by_set(NK);
+        if (NK >= (1ULL << 32)) { err = "more than 2^32 k-mers"; return CLS_E_BAD_DB; }
+        for (uint64_t j = 0; j < NK; ++j) by_set[j] = (uint32_t)j;
+        auto tips_of = [&](uint32_t j, uint32_t& n) { const uint32_t* w = &E.postings[kmer_off[j]]; n = w[0] & POST_LEN_MASK; return w + POST_HEADER_WORDS; };
+        auto cmp = [&](uint32_t a, uint32_t b) {
+            if (sig[a] != sig[b]) return sig[a] < sig[b];
+            uint32_t na, nb;
+            const uint32_t* ta = tips_of(a, na);
+            const uint32_t* tb = tips_of(b, nb);
+            if (na != nb) return na < nb;
+            const int c = na ? memcmp(ta, tb, (size_t)na * 4) : 0;
+            return c != 0 ? c < 0 : a < b;
+        };
+        parallel_sort(by_set, nt, cmp);
+        std::vector<uint32_t> set_of(NK), set_rep;  // k-mer -> set, set -> a k-mer that holds its tip list
+        std::vector<uint64_t> set_rec;                // set -> first split-node record
+        uint64_t n_recs = SPLIT_FIRST_REC + SPLIT_HEADER_RECS * NK;  // records 0/1: the dummy "no k-mer" header; then every k-mer's header
+        for (uint64_t i = 0; i < NK; ++i) {
+            const uint32_t j = by_set[i];
+            bool same = false;
+            if (i) {
+                const uint32_t p = by_set[i - 1];
+                uint32_t na, nb;
+                const uint32_t* ta = tips_of(p, na);
+                const uint32_t* tb = tips_of(j, nb);
+                same = sig[p] == sig[j] && na == nb && (na == 0 || memcmp(ta, tb, (size_t)na * 4) == 0);
+            }
+            if (!same) {
+                uint32_t n;
+                (void)tips_of(j, n);
+                set_rep.push_back(j);
+                set_rec.push_back(n_recs);
+                n_recs += n ? n - 1 : 0;
+            }
+            set_of[j] = (uint32_t)(set_rep.size() - 1);
+        }
+        std::vector<uint64_t>().swap(sig);
+        std::vector<uint32_t>().swap(by_set);
+        if (n_recs >= (1ULL << 31)) { err = "split-tree postings exceed 2^31 records"; return CLS_E_BAD_DB; }
+        const uint64_t NS = set_rep.size();
+        E.n_sets = NS;
+        std::vector<uint32_t> recs((n_recs + 1) * 4, 0);
+        recs[2] = 0xFFFFFFFFu;  // dummy header {0, 0, first tip = MAX, last tip = 0}: decodes to "inactive"
+        std::vector<uint32_t> set_root(NS, 0);
+        parallel_chunks(NS, nt, [&](unsigned, uint64_t lo, uint64_t hi) {
+            std::vector<uint32_t> d, stk, L, R, pos, span_lo, span_hi;
+            for (uint64_t g = lo; g < hi; ++g) {
+                uint32_t n;
+                const uint32_t* tip = tips_of(set_rep[g], n);
+                const uint64_t base = set_rec[g];
                 d.assign(n, 0); L.assign(n, 0); R.assign(n, 0);
                 for (uint32_t i = 1; i < n; ++i) {  // depth of LCA(tip[i-1], tip[i])
                     uint32_t a = tip[i - 1];
@@ -260,16 +327,8 @@ int encode_db(const cls_db_desc* d, EncodedDb& E, std::string& err) {
                         else { if (l) stk.push_back(l); if (r) stk.push_back(r); }
                     }
                 }
-                auto at = [&](uint32_t i) { return (uint32_t)(base + SPLIT_HEADER_RECS + pos[i]); };
-                uint32_t* h = &recs[base * 4];
-                h[0] = w[0];
-                h[1] = root ? at(root) : 0;
-                h[2] = n ? tip[0] : 0xFFFFFFFFu;  // no tip below the root: the "inactive" state {MAX, 0}
-                h[3] = n ? tip[n - 1] : 0;
-                h[4] = w[1];  // n_leaf_ids (statistics)
-                h[5] = (uint32_t)d_kmer_hash[j];
-                h[6] = (uint32_t)(d_kmer_hash[j] >> 32);
-                h[7] = bucket_of[j];
+                auto at = [&](uint32_t i) { return (uint32_t)(base + pos[i]); };
+                set_root[g] = root ? at(root) : 0;
                 for (uint32_t i = 1; i < n; ++i) {
                     uint32_t* t = &recs[(size_t)at(i) * 4];
                     t[0] = tip[i - 1];              // descending into the LEFT part: new last tip ...
@@ -279,8 +338,24 @@ int encode_db(const cls_db_desc* d, EncodedDb& E, std::string& err) {
                 }
             }
         });
+        parallel_chunks(NK, nt, [&](unsigned, uint64_t lo, uint64_t hi) {
+            for (uint64_t j = lo; j < hi; ++j) {
+                const uint32_t* w = &E.postings[kmer_off[j]];
+                const uint32_t n = w[0] & POST_LEN_MASK;
+                const uint32_t* tip = w + POST_HEADER_WORDS;
+                uint32_t* h = &recs[(SPLIT_FIRST_REC + SPLIT_HEADER_RECS * j) * 4];
+                h[0] = w[0];
+                h[1] = set_root[set_of[j]];
+                h[2] = n ? tip[0] : 0xFFFFFFFFu;  // no tip below the root: the "inactive" state {MAX, 0}
+                h[3] = n ? tip[n - 1] : 0;
+                h[4] = w[1];  // n_leaf_ids (statistics)
+                h[5] = (uint32_t)d_kmer_hash[j];
+                h[6] = (uint32_t)(d_kmer_hash[j] >> 32);
+                h[7] = bucket_of[j];
+            }
+        });
         E.postings.swap(recs);
-        kmer_off.assign(rec_off.begin(), rec_off.end() - 1);
+        for (uint64_t j = 0; j < NK; ++j) kmer_off[j] = SPLIT_FIRST_REC + SPLIT_HEADER_RECS * j;
     }
     // ---- 5. hash table -------------------------------------------------------------
     uint64_t cap = 16;

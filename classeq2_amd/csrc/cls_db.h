@@ -20,6 +20,7 @@ struct EncodedDb {
     uint32_t k = 0, m = 0, m_eff = 0;
     uint32_t max_depth = 0, max_nonleaf_arity = 0;
     uint64_t n_kmers = 0, n_closed = 0;
+    uint64_t n_sets = 0;              // FMT_SPLIT: distinct tip lists (k-mers with the same one share a split tree)
     bool root_has_children = false;
 };
 

@@ -171,7 +171,7 @@ typedef struct cls_db_info {
     uint32_t format;           /* 0: sorted lists (some node set is not closed under `parent`); 1: split-tree records */
     uint32_t binary_tree;      /* 1: every clade has zero or two children        */
     uint32_t direct_table;     /* 1: 2-bit-code direct table in use (k <= 15)    */
-    uint32_t pad_;
+    uint32_t n_tip_sets;       /* format 1: distinct tip lists (k-mers with the same one share a split tree) */
 } cls_db_info;
 
 /* Number of usable HIP devices (0 if none). */

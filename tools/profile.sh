@@ -1,0 +1,21 @@
+#!/bin/bash
+# Profiling recipe of this repo (run on the GPU box through gpurun): kernel trace + two PMC passes of bench.py.
+# usage: bash tools/profile.sh <tag>      -> gpurun_out/<tag>/..., summary JSON/CSV to copy into profiles/
+set -e
+TAG=${1:-prof}
+OUT=$PWD/gpurun_out/$TAG
+mkdir -p "$OUT"
+export TMPDIR=/tmp
+BENCH="python3 $PWD/bench.py --steps 5 --warmup 2 --no-cpu-baseline"
+cd /tmp
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d "$OUT/kt" -o kt --output-format csv -- $BENCH > "$OUT/bench_kt.json" 2> "$OUT/kt.err"
+timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE -d "$OUT/pmc_fetch" -o fetch --output-format csv -- $BENCH > /dev/null 2> "$OUT/pmc_fetch.err"
+timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum -d "$OUT/pmc_tcc" -o tcc --output-format csv -- $BENCH > /dev/null 2> "$OUT/pmc_tcc.err"
+cd - > /dev/null
+timeout -k 10 200 $BENCH > "$OUT/bench.json" 2> "$OUT/bench.err"
+python3 tools/pmc_summary.py "$OUT" > "$OUT/pmc_summary.json"
+find "$OUT" -name "*kernel_stats.csv" -exec cp {} "$OUT/kernel_stats.csv" \;
+rm -rf "$OUT"/pmc_fetch/*agent_info* "$OUT"/pmc_tcc/*agent_info*
+find "$OUT" -name "*kernel_trace.csv" -delete
+find "$OUT" -name "*counter_collection.csv" -delete
+cat "$OUT/pmc_summary.json"
