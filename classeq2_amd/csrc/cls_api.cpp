@@ -150,6 +150,7 @@ extern "C" int cls_db_create(const cls_db_desc* d, int device, cls_db** out) {
         v.max_nonleaf_arity = E.max_nonleaf_arity;
         v.format = E.format;
         v.binary_tree = E.strictly_binary ? 1u : 0u;
+        v.canonical = E.canonical ? 1u : 0u;
         v.addr32 = (E.postings.size() * 4 < (1ull << 32) && E.direct.size() * 4 < (1ull << 32)) ? 1u : 0u;
         cls_db_info& i = db->info;
         i.n_nodes = v.n_nodes;
@@ -167,7 +168,7 @@ extern "C" int cls_db_create(const cls_db_desc* d, int device, cls_db** out) {
         i.device = device;
         i.format = E.format;
         i.binary_tree = E.strictly_binary ? 1u : 0u;
-        i.direct_table = E.direct.empty() ? 0u : 1u;
+        i.direct_table = E.direct.empty() ? 0u : (E.canonical ? 2u : 1u);
         i.n_tip_sets = (uint32_t)E.n_sets;
         *out = db;
         return CLS_OK;

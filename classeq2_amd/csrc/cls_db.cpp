@@ -416,6 +416,22 @@ int encode_db(const cls_db_desc* d, EncodedDb& E, std::string& err) {
         // an entry filed under a bucket that is not its own prefix's, or a hash no enumerated k-mer
         // produces (k-mers with non-ACGT letters cannot be queried anyway): keep the generic probe path
         if (foreign.load() || found.load() != NK) std::vector<uint32_t>().swap(E.direct);
+        if (!E.direct.empty()) {
+            // does every k-mer share its state (tip set, root flag) with its reverse complement?  True for an index
+            // built from both strands; the fast kernel then looks up one k-mer per window instead of two.
+            std::atomic<bool> asym{false};
+            parallel_chunks(n_codes, nt, [&](unsigned, uint64_t lo, uint64_t hi) {
+                for (uint64_t code = lo; code < hi && !asym.load(std::memory_order_relaxed); ++code) {
+                    uint64_t rc = 0;
+                    for (uint32_t i = 0; i < K; ++i) rc |= (((code >> (2 * i)) & 3) ^ 2) << (2 * (K - 1 - i));  // complement = code ^ 2 (A0 <-> T2, C1 <-> G3)
+                    if (rc <= code) continue;
+                    const uint32_t* a = &E.direct[4 * code];
+                    const uint32_t* b = &E.direct[4 * rc];
+                    if ((a[0] != 0) != (b[0] != 0) || a[1] != b[1] || a[2] != b[2] || a[3] != b[3]) asym = true;
+                }
+            });
+            E.canonical = !asym.load();
+        }
     }
     E.bucket_key.assign(d->bucket_key, d->bucket_key + d->n_buckets);
     if (E.bucket_key.empty()) E.bucket_key.push_back(0);

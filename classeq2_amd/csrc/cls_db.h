@@ -15,6 +15,7 @@ struct EncodedDb {
     std::vector<uint32_t> postings;   // FMT_LIST words, or FMT_SPLIT records (4 words each)
     uint32_t format = FMT_LIST;
     bool strictly_binary = false;
+    bool canonical = false;           // direct table symmetric under reverse complement
     std::vector<uint64_t> bucket_key;
     std::vector<uint32_t> direct;     // 4^k x {record offset, meta} (FMT_SPLIT, k <= DIRECT_MAX_K) or empty
     uint32_t k = 0, m = 0, m_eff = 0;

@@ -10,6 +10,7 @@ namespace cls {
 struct PlacePlan {
     uint32_t grid[2];          // workgroups per wave-per-read class
     uint32_t grid_blk;         // workgroups of the workgroup-per-read class
+    uint32_t grid_key;         // workgroups of the locality-key kernel
     bool ordered;              // class-0 reads are processed in locality order (fast path, large batches)
     uint64_t keys_off_words;   // sort keys / indices
     uint64_t sort_off_words;   // radix-sort scratch

@@ -30,6 +30,9 @@ constexpr int WAVES_PER_BLOCK = 4;
 #ifndef MIN_WAVES_PER_EU
 #define MIN_WAVES_PER_EU 4
 #endif
+#ifndef FAST_MIN_WAVES
+#define FAST_MIN_WAVES 5  // 96 VGPRs: 5 workgroups per CU measured best on C3 (4: 9.2 ms, 5: 8.5, 6: 9.1 with more spills)
+#endif
 constexpr uint32_t SET_EMPTY = 0xFFFFFFFFu;
 
 __device__ __forceinline__ void wave_sync() {
@@ -938,15 +941,20 @@ struct FastCtx {
     uint8_t* ascii;    // LDS: upper-cased read, L bytes
     uint32_t* packed;  // LDS: the read 2 bits per base, base i at bits 2(i & 15) of word i >> 4
     uint32_t* set;     // LDS: distinct-hit set keyed by header record offset
+    uint32_t* gkey;    // LDS: tip-set groups of the read's k-mers: key (root split, or the single tip) ...
+    uint32_t* gcnt;    // ... and how many distinct k-mers carry it
+    uint4* stage;      // LDS: the groups compacted {first tip, last tip, split, weight}; lies over set/gkey/gcnt
 };
 
 // Front of the fast path, shared with order_key_kernel: the read -> LDS (upper-cased, validated),
 // 2 bits per base, then per query k-mer its 2-bit code and the direct-table entry
 // {header offset, root split, first tip | bit length << 27, last tip | has_root << 31}.
+// `canonical`: one lookup per window j < nk = nf, of the smaller of the k-mer and its reverse complement;
+// kw = how many distinct query k-mers the lookup stands for (2, or 1 for a palindrome).
 // Returns false if the read holds a character other than ACGT.
 template <int SLOTS, int SET_BITS, bool ADDR32>
 __device__ __forceinline__ bool fast_front(const DbDev& db, const FastCtx& cx, const uint8_t* __restrict__ bases, uint64_t b0,
-                                           uint32_t L, uint32_t nf, uint32_t nk, uint4 (&ent)[SLOTS],
+                                           uint32_t L, uint32_t nf, uint32_t nk, uint4 (&ent)[SLOTS], uint32_t (&kw)[SLOTS],
                                            uint32_t sample_shift = 32, bool canonical = false) {
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t k = db.k;
@@ -959,7 +967,10 @@ __device__ __forceinline__ bool fast_front(const DbDev& db, const FastCtx& cx, c
         cx.ascii[i] = c;
     }
 #pragma unroll 1
-    for (uint32_t i = lane; i < (1u << SET_BITS); i += 64) cx.set[i] = SET_EMPTY;
+    for (uint32_t i = lane; i < (1u << SET_BITS); i += 64) {
+        cx.set[i] = SET_EMPTY;
+        if (SET_BITS) { cx.gkey[i] = SET_EMPTY; cx.gcnt[i] = 0; }
+    }
     if (__ballot(bad)) return false;
     wave_sync();
     {
@@ -993,17 +1004,19 @@ __device__ __forceinline__ bool fast_front(const DbDev& db, const FastCtx& cx, c
         uint32_t rcc = __builtin_bitreverse32(code ^ (0xAAAAAAAAu & kmask));
         rcc = ((rcc >> 1) & 0x55555555u) | ((rcc & 0x55555555u) << 1);
         rcc >>= (32 - 2 * k);
+        const bool palindrome = code == rcc;
         code = canonical ? (rcc < code ? rcc : code) : (rc ? rcc : code);  // canonical: the same entry whichever strand was read
         // sample_shift < 32: look up only the k-mers whose scrambled code has its top bits clear (a content-
         // based sample, the same k-mers in every read that contains them); 32 = all
         const bool take = valid && (sample_shift >= 32 || ((code * 0x9E3779B1u) >> sample_shift) == 0);
         const uint4 e = ldx<uint4, ADDR32>(direct, take ? code : 0u);
         ent[s] = take ? e : uint4{0u, 0u, 0xFFFFFFFFu, 0u};
+        kw[s] = !take ? 0u : (canonical && !palindrome) ? 2u : 1u;  // canonical: the window stands for the k-mer and its reverse complement
     }
     return true;
 }
 
-template <int SLOTS, int SET_BITS, bool STATS, bool ADDR32>
+template <int SLOTS, int SET_BITS, bool STATS, bool ADDR32, bool CANON>
 __device__ __forceinline__ void place_read_fast(const DbDev& db, const PlaceParams& prm, const FastCtx& cx,
                                                 const uint8_t* __restrict__ bases, uint64_t b0, uint64_t b1, uint32_t r,
                                                 cls_placement* __restrict__ out, cls_query_stats* __restrict__ stats,
@@ -1022,8 +1035,13 @@ __device__ __forceinline__ void place_read_fast(const DbDev& db, const PlacePara
     if (L64 < k) { put_stats(0, 0, 0, 0); write_record(out, r, CLS_ERR_TOO_FEW_KMERS, 0, 0, 0, 0); return; }
     const uint32_t L = (uint32_t)L64, nf = L - k + 1, nk = 2 * nf;  // nk <= 64*SLOTS by classification
     // ---- A1/A2. load + validate + 2-bit pack; per k-mer: code -> direct table ----------------------
-    uint4 ent[SLOTS];
-    if (!fast_front<SLOTS, SET_BITS, ADDR32>(db, cx, bases, b0, L, nf, nk, ent)) {
+    // CANON (an index in which every k-mer and its reverse complement carry the same tip set, i.e. one built from
+    // both strands): the k-mers of window p on the two strands are reverse complements of each other, so ONE lookup
+    // of the smaller of the two answers for both; half the lookups, half the slots.
+    constexpr int LS = CANON ? (SLOTS + 1) / 2 : SLOTS;
+    uint4 ent[LS];
+    uint32_t kw[LS];
+    if (!fast_front<LS, SET_BITS, ADDR32>(db, cx, bases, b0, L, nf, CANON ? nf : nk, ent, kw, 32, CANON)) {
         put_stats(0, 0, 0, 0);
         write_record(out, r, CLS_ERR_INVALID_BASE, 0, 0, 0, 0);
         return;
@@ -1031,7 +1049,7 @@ __device__ __forceinline__ void place_read_fast(const DbDev& db, const PlacePara
     const uint32_t* __restrict__ recs = db.postings;
     // distinct hashes: the FIRST k-mer that reaches an entry keeps it (HashSet<u64> semantics)
 #pragma unroll
-    for (int s = 0; s < SLOTS; ++s) {
+    for (int s = 0; s < LS; ++s) {
         if (ent[s].x != 0) {
             const uint32_t key = ent[s].x;
             uint32_t pos = (key * 2654435761u) >> (32 - SET_BITS);
@@ -1039,23 +1057,19 @@ __device__ __forceinline__ void place_read_fast(const DbDev& db, const PlacePara
             for (;;) {
                 const uint32_t old = atomicCAS(&cx.set[pos], SET_EMPTY, key);
                 if (old == SET_EMPTY) break;
-                if (old == key) { ent[s] = uint4{0u, 0u, 0xFFFFFFFFu, 0u}; break; }
+                if (old == key) { ent[s] = uint4{0u, 0u, 0xFFFFFFFFu, 0u}; kw[s] = 0; break; }
                 pos = (pos + 1) & ((1u << SET_BITS) - 1);
             }
         }
     }
-    if (profile_stop == 1) { write_record(out, r, 0xFE, (int32_t)(ent[0].x + ent[SLOTS - 1].x), 0, 0, 0); return; }  // profiling aid
-    // ---- A3. the descent state comes with the table entry: no header read -----------------------------
-    uint32_t vlo[SLOTS], vhi[SLOTS], x[SLOTS];
+    if (profile_stop == 1) { write_record(out, r, 0xFE, (int32_t)(ent[0].x + ent[LS - 1].x), 0, 0, 0); return; }  // profiling aid
+    // ---- A3. |M|, |M_root| (the descent state comes with the table entry: no header read) -----------------
     uint32_t cnt = 0;  // |M| in bits 0..15, |M_root| in bits 16..31 (per lane, then summed)
     uint64_t leafp = 0;
 #pragma unroll
-    for (int s = 0; s < SLOTS; ++s) {
-        if (STATS) leafp += ldx<uint4, ADDR32>(recs, ent[s].x + 1).x;  // record 1 (the dummy's second half) holds 0
-        vlo[s] = ent[s].z & DIRECT_TIP_MASK;  // absent / tip-less: the largest value, above every interval bound
-        vhi[s] = ent[s].w & 0x7FFFFFFFu;
-        x[s] = ent[s].y;
-        cnt += (ent[s].x != 0 ? 1u : 0u) + ((ent[s].w >> 31) << 16);
+    for (int s = 0; s < LS; ++s) {
+        if (STATS) leafp += (uint64_t)kw[s] * ldx<uint4, ADDR32>(recs, ent[s].x + 1).x;  // record 1 (the dummy's second half) holds 0
+        cnt += (ent[s].x != 0 ? kw[s] : 0u) + ((ent[s].w >> 31) * kw[s] << 16);
     }
     cnt = wave_sum(cnt);
     const uint32_t n_m = cnt & 0xFFFFu, n_root = cnt >> 16;
@@ -1063,7 +1077,7 @@ __device__ __forceinline__ void place_read_fast(const DbDev& db, const PlacePara
         for (int o = 32; o > 0; o >>= 1) leafp += ((uint64_t)__shfl_xor((uint32_t)(leafp >> 32), o) << 32) | __shfl_xor((uint32_t)leafp, o);
         put_stats(nk, n_m, n_root, leafp);
     }
-    if (profile_stop == 2) { write_record(out, r, 0xFE, (int32_t)(vlo[0] + vhi[SLOTS - 1] + x[1]), 0, 0, 0); return; }
+    if (profile_stop == 2) { write_record(out, r, 0xFE, (int32_t)(ent[0].z + ent[LS - 1].w), 0, 0, 0); return; }
     // ---- B. thresholds ------------------------------------------------------------------------------
     if (n_m == 0) { write_record(out, r, CLS_UNCLASSIFIABLE_NO_MATCH, 0, 0, 0, 0); return; }
     if (n_root == 0) { write_record(out, r, CLS_UNCLASSIFIABLE_NO_ROOT, 0, 0, 0, 0); return; }
@@ -1075,9 +1089,57 @@ __device__ __forceinline__ void place_read_fast(const DbDev& db, const PlacePara
         const uint64_t exp_usize = (expected != expected) ? 0ull : (uint64_t)expected;
         if ((uint64_t)n_root < exp_usize) { write_record(out, r, CLS_UNCLASSIFIABLE_COVERAGE, (int32_t)n_root, 0, 0, 0); return; }
     }
+    // ---- A4. group the k-mers by tip set ----------------------------------------------------------------
+    // k-mers with the same tip list (they share their split tree: same root split, or the same single tip)
+    // stay together all the way down, so the descent runs on {set, number of k-mers} pairs: a 150 bp read
+    // has a few dozen of them.  The first k-mer to claim a key owns the group; the groups are compacted into
+    // the staging area (64 per chunk; chunk 0 then lives in registers, the others stay in LDS).
+    uint32_t n_sets = 0;
+    {
+        uint32_t pos[LS];
+        uint32_t owner = 0;
+#pragma unroll
+        for (int s = 0; s < LS; ++s) {
+            const uint32_t lo_ = ent[s].z & DIRECT_TIP_MASK, hi_ = ent[s].w & 0x7FFFFFFFu;
+            pos[s] = 0;
+            if (lo_ <= hi_) {  // has tips below the root (absent / tip-less entries hold {MAX, 0})
+                const uint32_t key = ent[s].y ? ent[s].y : (0x80000000u | lo_);
+                uint32_t p = (key * 2654435761u) >> (32 - SET_BITS);
+#pragma unroll 1
+                for (;;) {
+                    const uint32_t old = atomicCAS(&cx.gkey[p], SET_EMPTY, key);
+                    if (old == SET_EMPTY) { owner |= 1u << s; break; }
+                    if (old == key) break;
+                    p = (p + 1) & ((1u << SET_BITS) - 1);
+                }
+                atomicAdd(&cx.gcnt[p], kw[s]);
+                pos[s] = p;
+            }
+        }
+        wave_sync();
+#pragma unroll
+        for (int s = 0; s < LS; ++s) pos[s] = ((owner >> s) & 1u) ? cx.gcnt[pos[s]] : 0u;  // now: the group's weight
+        wave_sync();  // the tables are dead from here on: the staging area lies over them
+#pragma unroll
+        for (int s = 0; s < LS; ++s) {
+            const uint64_t m = __ballot((owner >> s) & 1u);
+            if ((owner >> s) & 1u)
+                cx.stage[n_sets + popc64(m & ((1ull << lane) - 1))] = uint4{ent[s].z & DIRECT_TIP_MASK, ent[s].w & 0x7FFFFFFFu, ent[s].y, pos[s]};
+            n_sets += popc64(m);
+        }
+    }
+    const uint32_t n_chunks = uniform((n_sets + 63) >> 6);  // wave-uniform; >= 1 here (some k-mer has the root and tips... or none: then 0)
+    if (n_sets + lane < 64 * n_chunks) cx.stage[n_sets + lane] = uint4{0xFFFFFFFFu, 0u, 0u, 0u};  // pad the last chunk with inactive entries
+    wave_sync();
+    uint32_t vlo, vhi, x, wt;  // chunk 0
+    {
+        const uint4 g = n_chunks ? cx.stage[lane] : uint4{0xFFFFFFFFu, 0u, 0u, 0u};
+        vlo = g.x; vhi = g.y; x = g.z; wt = g.w;
+    }
     // ---- C. descent -----------------------------------------------------------------------------------
     const uint32_t* __restrict__ half = db.postings;  // record x = 8-byte halves 2x (left part), 2x+1 (right part)
     const bool rm = prm.remove_intersection != 0;
+    constexpr bool PACK10 = SLOTS * 64 < 1024;  // three 10-bit counters in one word
     int32_t iteration = 0;
     for (;;) {
         ++iteration;
@@ -1086,16 +1148,19 @@ __device__ __forceinline__ void place_read_fast(const DbDev& db, const PlacePara
         const uint32_t a0 = P.s[0] + 1, a1 = P.s[6];  // first child = [a0, a1), second = [a1, end of the parent)
         // both children's records, requested ahead of the counting
         const snode_t CA = load_node(db.nodes, fc), CB = load_node(db.nodes, fc + 1);
-        uint32_t c3 = 0, c3b = 0;  // per lane: |in a| | |in b| << 10 | |in both| << 20
-#pragma unroll
-        for (int s = 0; s < SLOTS; ++s) {
-            const uint32_t ina = vlo[s] < a1 ? 1u : 0u;   // vlo >= a0 for an active k-mer, MAX for an inactive one
-            const uint32_t inb = vhi[s] >= a1 ? 1u : 0u;  // vhi < end of the parent for an active one, 0 for an inactive one
-            if (SLOTS * 64 < 1024) c3 += ina | (inb << 10) | ((ina & inb) << 20);
-            else { c3 += ina | (inb << 16); c3b += ina & inb; }
-        }
+        uint32_t c3 = 0, c3b = 0;  // per lane: k-mers in a | in b << 10 | in both << 20
+        auto count = [&](uint32_t lo_, uint32_t hi_, uint32_t w) {
+            const uint32_t ina = lo_ < a1 ? w : 0u;    // lo >= a0 for an active set, MAX for an inactive one
+            const uint32_t inb = hi_ >= a1 ? w : 0u;   // hi < end of the parent for an active one, 0 for an inactive one
+            const uint32_t bo = (lo_ < a1 && hi_ >= a1) ? w : 0u;
+            if (PACK10) c3 += ina | (inb << 10) | (bo << 20);
+            else { c3 += ina | (inb << 16); c3b += bo; }
+        };
+        count(vlo, vhi, wt);
+#pragma unroll 1
+        for (uint32_t c = 1; c < n_chunks; ++c) { const uint4 g = cx.stage[c * 64 + lane]; count(g.x, g.y, g.w); }
         uint32_t cnt_a, cnt_b, both;
-        if (SLOTS * 64 < 1024) {
+        if (PACK10) {
             c3 = wave_sum(c3);
             cnt_a = c3 & 0x3FFu; cnt_b = (c3 >> 10) & 0x3FFu; both = c3 >> 20;
         } else {
@@ -1122,53 +1187,48 @@ __device__ __forceinline__ void place_read_fast(const DbDev& db, const PlacePara
                          ((uint64_t)P.s[5] << 32) | P.s[4]);
             return;
         }
-        // narrow: a k-mer with tips on both sides of a1 reads 8 bytes of its split node; everything else
-        // is arithmetic on (vlo, vhi).  Inactive afterwards = {MAX, 0}.
-        if (!right) {
-            uint2 t[SLOTS];
-#pragma unroll
-            for (int s = 0; s < SLOTS; ++s) {
-                const bool str = vlo[s] < a1 && vlo[s] != a0 && vhi[s] >= a1;
-                t[s] = profile_stop == 3 ? uint2{vhi[s] >> 1, x[s]} : ldx<uint2, ADDR32>(half, str ? 2 * x[s] : 0u);
+        // narrow: a set with tips on both sides of a1 reads 8 bytes of its split node (the half for the side
+        // taken); everything else is arithmetic on (lo, hi).  Inactive afterwards = {MAX, 0}.
+        auto narrow = [&](uint32_t& lo_, uint32_t& hi_, uint32_t& x_) {
+            const bool str = lo_ < a1 && hi_ >= a1 && (right || lo_ != a0);
+            const uint2 t = ldx<uint2, ADDR32>(half, str ? 2 * x_ + (right ? 1u : 0u) : 0u);
+            if (!right) {
+                const bool gone = lo_ >= a1 || lo_ == a0;  // no tip strictly below the first child
+                if (str) { hi_ = t.x; x_ = t.y; }
+                if (gone) { lo_ = 0xFFFFFFFFu; hi_ = 0; }
+            } else {
+                if (str) { lo_ = t.x; x_ = t.y; }
+                const bool gone = hi_ < a1 || lo_ == a1;  // nothing in the second child, or it is the tip itself
+                if (gone) { lo_ = 0xFFFFFFFFu; hi_ = 0; }
             }
-#pragma unroll
-            for (int s = 0; s < SLOTS; ++s) {
-                const bool gone = vlo[s] >= a1 || vlo[s] == a0;  // no tip strictly below the first child
-                const bool str = !gone && vhi[s] >= a1;
-                if (str) { vhi[s] = t[s].x; x[s] = t[s].y; }
-                if (gone) { vlo[s] = 0xFFFFFFFFu; vhi[s] = 0; }
-            }
-        } else {
-            uint2 t[SLOTS];
-#pragma unroll
-            for (int s = 0; s < SLOTS; ++s) {
-                const bool str = vhi[s] >= a1 && vlo[s] < a1;
-                t[s] = profile_stop == 3 ? uint2{vlo[s] + 1, x[s]} : ldx<uint2, ADDR32>(half, str ? 2 * x[s] + 1 : 0u);
-            }
-#pragma unroll
-            for (int s = 0; s < SLOTS; ++s) {
-                const bool str = vhi[s] >= a1 && vlo[s] < a1;
-                if (str) { vlo[s] = t[s].x; x[s] = t[s].y; }
-                const bool gone = vhi[s] < a1 || vlo[s] == a1;  // nothing in the second child, or it is the tip itself
-                if (gone) { vlo[s] = 0xFFFFFFFFu; vhi[s] = 0; }
-            }
+        };
+        narrow(vlo, vhi, x);
+#pragma unroll 1
+        for (uint32_t c = 1; c < n_chunks; ++c) {
+            uint4 g = cx.stage[c * 64 + lane];
+            narrow(g.x, g.y, g.z);
+            cx.stage[c * 64 + lane] = g;
         }
     }
 }
 
-template <int SLOTS, int SET_BITS, bool STATS, bool ADDR32>
-__global__ __launch_bounds__(64 * WAVES_PER_BLOCK, MIN_WAVES_PER_EU) void place_fast_kernel(
+template <int SLOTS, int SET_BITS, bool STATS, bool ADDR32, bool CANON>
+__global__ __launch_bounds__(64 * WAVES_PER_BLOCK, FAST_MIN_WAVES) void place_fast_kernel(
     DbDev db, PlaceParams prm, const uint8_t* __restrict__ bases, const uint64_t* __restrict__ offsets,
     const uint32_t* __restrict__ list, const uint32_t* __restrict__ list_len, uint32_t list_n, uint32_t xcd_chunks,
     cls_placement* __restrict__ out, cls_query_stats* __restrict__ stats, uint32_t ascii_cap, uint32_t profile_stop) {
     extern __shared__ __align__(16) uint8_t smem[];
     const uint32_t wave = threadIdx.x >> 6;
-    const uint32_t packed_words = (ascii_cap >> 4) + 2;
-    const uint32_t per_wave = ascii_cap + 4u * packed_words + (4u << SET_BITS);
+    const uint32_t packed_words = ((ascii_cap >> 4) + 2 + 3) & ~3u;  // whole 16-byte units: what follows stays 16-byte aligned
+    static_assert((12u << SET_BITS) >= 16u * 64 * SLOTS, "the staging area must fit over the three tables");
+    const uint32_t per_wave = ascii_cap + 4u * packed_words + (12u << SET_BITS);
     FastCtx cx;
     cx.ascii = smem + wave * per_wave;
     cx.packed = reinterpret_cast<uint32_t*>(cx.ascii + ascii_cap);
     cx.set = cx.packed + packed_words;
+    cx.gkey = cx.set + (1u << SET_BITS);
+    cx.gcnt = cx.gkey + (1u << SET_BITS);
+    cx.stage = reinterpret_cast<uint4*>(cx.set);
     if (xcd_chunks) {
         // locality-ordered list: XCD x (workgroups with blockIdx % 8 == x share an L2) walks the x-th
         // eighth of the list front to back, so that reads processed together share cache lines
@@ -1183,7 +1243,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, MIN_WAVES_PER_EU) void place_
             const uint64_t b0 = offsets[r], b1 = offsets[r + 1];
             const uint64_t L64 = b1 - b0;
             if (L64 >= db.k && 2 * (L64 - db.k + 1) > cap) continue;  // another class' read (classify_kernel binned it)
-            place_read_fast<SLOTS, SET_BITS, STATS, ADDR32>(db, prm, cx, bases, b0, b1, r, out, stats, profile_stop);
+            place_read_fast<SLOTS, SET_BITS, STATS, ADDR32, CANON>(db, prm, cx, bases, b0, b1, r, out, stats, profile_stop);
             wave_sync();
         }
         return;
@@ -1194,7 +1254,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, MIN_WAVES_PER_EU) void place_
     for (uint32_t i = gw; i < n_list; i += n_waves) {
         const uint32_t r = list[i];
         const uint64_t b0 = offsets[r], b1 = offsets[r + 1];
-        place_read_fast<SLOTS, SET_BITS, STATS, ADDR32>(db, prm, cx, bases, b0, b1, r, out, stats, profile_stop);
+        place_read_fast<SLOTS, SET_BITS, STATS, ADDR32, CANON>(db, prm, cx, bases, b0, b1, r, out, stats, profile_stop);
         wave_sync();
     }
 }
@@ -1211,12 +1271,14 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void order_key_kernel(DbDev d
                                                                        uint32_t block_shift, uint32_t sample_shift, uint32_t fwd_only) {
     extern __shared__ __align__(16) uint8_t smem[];
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const uint32_t packed_words = (ascii_cap >> 4) + 2;
+    const uint32_t packed_words = ((ascii_cap >> 4) + 2 + 3) & ~3u;  // whole 16-byte units: what follows stays 16-byte aligned
     const uint32_t per_wave = ascii_cap + 4u * packed_words + 16u;
     FastCtx cx;
     cx.ascii = smem + wave * per_wave;
     cx.packed = reinterpret_cast<uint32_t*>(cx.ascii + ascii_cap);
     cx.set = cx.packed + packed_words;  // 1 dummy entry (SET_BITS = 0)
+    cx.gkey = cx.gcnt = nullptr;
+    cx.stage = nullptr;
     const uint32_t gw = blockIdx.x * WAVES_PER_BLOCK + wave;
     const uint32_t n_waves = gridDim.x * WAVES_PER_BLOCK;
     for (uint32_t r = gw; r < n_reads; r += n_waves) {
@@ -1225,9 +1287,10 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void order_key_kernel(DbDev d
         if (L64 >= db.k && 2 * (L64 - db.k + 1) <= (uint64_t)(64 * SLOTS)) {
             const uint32_t L = (uint32_t)L64, nf = L - db.k + 1, nk = 2 * nf;
             uint4 ent[SLOTS];
+            uint32_t kw[SLOTS];
             // one lookup per window, of the smaller of the k-mer and its reverse complement: an index built from
             // both strands files the two under the same leaves, and the key then does not depend on the strand read
-            if (fast_front<SLOTS, 0, ADDR32>(db, cx, bases, b0, L, nf, fwd_only ? nf : nk, ent, sample_shift, fwd_only != 0)) {
+            if (fast_front<SLOTS, 0, ADDR32>(db, cx, bases, b0, L, nf, fwd_only ? nf : nk, ent, kw, sample_shift, fwd_only != 0)) {
                 // candidates: k-mers present in the index that are specific to a small clade (few tips);
                 // the tip bound is widened until a handful qualify (finally: every k-mer present)
                 uint32_t cand = 0, n_cand = 0;
@@ -1663,7 +1726,7 @@ bool child_in_lds(const DbDev& db) { return child_ws_stride(db) != 0 && child_ws
 size_t smem_of(const DbDev& db, int c) {
     if (use_fast(db)) {
         const uint32_t ac = ascii_cap_of(db, c);
-        return (size_t)WAVES_PER_BLOCK * (ac + 4u * ((ac >> 4) + 2) + (4u << CLS_SET_BITS[c]));
+        return (size_t)WAVES_PER_BLOCK * (ac + 4u * (((ac >> 4) + 2 + 3) & ~3u) + (12u << CLS_SET_BITS[c]));
     }
     return (size_t)WAVES_PER_BLOCK * (seq_cap_of(db, c) + (4u << CLS_SET_BITS[c]) + 4u * 64 * CLS_SLOTS[c]) +
            (child_in_lds(db) ? (size_t)WAVES_PER_BLOCK * 2 * child_ws_stride(db) * 4 : 0);
@@ -1672,8 +1735,10 @@ size_t smem_of(const DbDev& db, int c) {
 template <int SLOTS, int SET_BITS>
 const void* kernel_of_t(const DbDev& db, bool stats) {
     if (use_fast(db)) {
-        if (db.addr32) return stats ? (const void*)place_fast_kernel<SLOTS, SET_BITS, true, true> : (const void*)place_fast_kernel<SLOTS, SET_BITS, false, true>;
-        return stats ? (const void*)place_fast_kernel<SLOTS, SET_BITS, true, false> : (const void*)place_fast_kernel<SLOTS, SET_BITS, false, false>;
+#define CLS_FAST_OF(A32, CN) (stats ? (const void*)place_fast_kernel<SLOTS, SET_BITS, true, A32, CN> : (const void*)place_fast_kernel<SLOTS, SET_BITS, false, A32, CN>)
+        if (db.addr32) return db.canonical ? CLS_FAST_OF(true, true) : CLS_FAST_OF(true, false);
+        return db.canonical ? CLS_FAST_OF(false, true) : CLS_FAST_OF(false, false);
+#undef CLS_FAST_OF
     }
     if (db.format == FMT_SPLIT) {
         if (db.binary_tree) return stats ? (const void*)place_split_kernel<SLOTS, SET_BITS, true, false> : (const void*)place_split_kernel<SLOTS, SET_BITS, false, false>;
@@ -1727,10 +1792,19 @@ PlacePlan plan_place(const DbDev& db, uint32_t n_reads, uint32_t n_cu, bool stat
     uint64_t w = 16 + 4 * (uint64_t)n_reads;
     w += w & 1;
     if (p.ordered) {
-        // 3 workgroups (12 reads) per CU measured best: more reads in flight per XCD evict each other's
-        // lines from its 4 MiB L2 faster than the extra latency hiding pays (2: 16.9 ms, 3: 15.9, 4: 19.0 on C3)
-        if (forced <= 0) p.grid[0] = std::min<uint32_t>(p.grid[0], 3 * n_cu);
+        // every resident workgroup (5 per CU at 96 VGPRs): since k-mers share split trees and the descent runs
+        // on tip-set groups, a read's footprint in the XCD's 4 MiB L2 is small enough that more reads in flight
+        // keep paying (C3: 2 per CU 15.5 ms, 3: 11.2, 4: 9.3; a grid beyond residency only adds a tail)
         p.grid[0] = std::max<uint32_t>(8, p.grid[0] & ~7u);  // whole octets of workgroups: one slice of the list per XCD
+        {   // the key kernel is bound by the latency of random table reads: every wave the CU can hold
+            static const int forced_key = [] { const char* e = getenv("CLS_KEY_BLOCKS_PER_CU"); return e ? atoi(e) : 0; }();
+            int per_cu = forced_key;
+            const uint32_t ac = ascii_cap_of(db, 0);
+            const size_t smem_k = (size_t)WAVES_PER_BLOCK * (ac + 4u * (((ac >> 4) + 2 + 3) & ~3u) + 16u);
+            const void* kfn = db.addr32 ? (const void*)order_key_kernel<CLS_SLOTS[0], true> : (const void*)order_key_kernel<CLS_SLOTS[0], false>;
+            if (per_cu <= 0 && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kfn, 64 * WAVES_PER_BLOCK, smem_k) != hipSuccess || per_cu <= 0)) per_cu = 4;
+            p.grid_key = std::max<uint32_t>(1, std::min<uint32_t>(want, n_cu * (uint32_t)per_cu));
+        }
         p.keys_off_words = w;
         w += 6 * (uint64_t)n_reads;
         p.sort_off_words = w;
@@ -1789,12 +1863,12 @@ hipError_t launch_place(const DbDev& db, const PlaceParams& prm, const PlacePlan
         static const uint32_t fwd_only = [] { const char* v = getenv("CLS_ORDER_BOTH_STRANDS"); return v ? 0u : 1u; }();
         static const uint32_t sample_shift = [] { const char* v = getenv("CLS_ORDER_SAMPLE_SHIFT"); return v ? (uint32_t)atoi(v) : 32u; }();
         static const uint32_t block_shift = [] { const char* v = getenv("CLS_ORDER_BLOCK_SHIFT"); return v ? (uint32_t)atoi(v) : 2u; }();
-        const size_t smem_k = (size_t)WAVES_PER_BLOCK * (ac + 4u * ((ac >> 4) + 2) + 16u);
+        const size_t smem_k = (size_t)WAVES_PER_BLOCK * (ac + 4u * (((ac >> 4) + 2 + 3) & ~3u) + 16u);
         if (db.addr32)
-            hipLaunchKernelGGL((order_key_kernel<CLS_SLOTS[0], true>), dim3(plan.grid[0]), dim3(64 * WAVES_PER_BLOCK), smem_k, stream, db,
+            hipLaunchKernelGGL((order_key_kernel<CLS_SLOTS[0], true>), dim3(plan.grid_key), dim3(64 * WAVES_PER_BLOCK), smem_k, stream, db,
                                d_bases, d_offsets, n_reads, keys_in, idx_in, ac, tip_bits, spec_lg, block_shift, sample_shift, fwd_only);
         else
-            hipLaunchKernelGGL((order_key_kernel<CLS_SLOTS[0], false>), dim3(plan.grid[0]), dim3(64 * WAVES_PER_BLOCK), smem_k, stream, db,
+            hipLaunchKernelGGL((order_key_kernel<CLS_SLOTS[0], false>), dim3(plan.grid_key), dim3(64 * WAVES_PER_BLOCK), smem_k, stream, db,
                                d_bases, d_offsets, n_reads, keys_in, idx_in, ac, tip_bits, spec_lg, block_shift, sample_shift, fwd_only);
         e = sort_pairs(d_ws + plan.sort_off_words, plan.sort_bytes, keys_in, keys_out, idx_in, idx_out, n_reads, ORDER_KEY_BITS, stream);
         if (e != hipSuccess) return e;
@@ -1811,11 +1885,13 @@ hipError_t launch_place(const DbDev& db, const PlaceParams& prm, const PlacePlan
             const uint32_t ac = ascii_cap_of(db, c);
             const uint32_t* lst = c == 0 ? list0 : lists[c];
             const uint32_t ln = c == 0 ? list0_n : 0u, xc = c == 0 ? xcd_chunks : 0u;
-#define CLS_LAUNCH_FAST(ST, A32)                                                                                              \
-    hipLaunchKernelGGL((place_fast_kernel<SLOTS, SET_BITS, ST, A32>), grid, block, smem, stream, db, prm, d_bases, d_offsets, \
+#define CLS_LAUNCH_FAST(ST, A32, CN)                                                                                              \
+    hipLaunchKernelGGL((place_fast_kernel<SLOTS, SET_BITS, ST, A32, CN>), grid, block, smem, stream, db, prm, d_bases, d_offsets, \
                        lst, counts + c, ln, xc, d_out, d_stats, ac, profile_stop)
-            if (db.addr32) { if (st) CLS_LAUNCH_FAST(true, true); else CLS_LAUNCH_FAST(false, true); }
-            else { if (st) CLS_LAUNCH_FAST(true, false); else CLS_LAUNCH_FAST(false, false); }
+#define CLS_LAUNCH_FAST2(ST, A32) do { if (db.canonical) CLS_LAUNCH_FAST(ST, A32, true); else CLS_LAUNCH_FAST(ST, A32, false); } while (0)
+            if (db.addr32) { if (st) CLS_LAUNCH_FAST2(true, true); else CLS_LAUNCH_FAST2(false, true); }
+            else { if (st) CLS_LAUNCH_FAST2(true, false); else CLS_LAUNCH_FAST2(false, false); }
+#undef CLS_LAUNCH_FAST2
 #undef CLS_LAUNCH_FAST
             return;
         }

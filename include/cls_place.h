@@ -170,7 +170,8 @@ typedef struct cls_db_info {
     int32_t device;
     uint32_t format;           /* 0: sorted lists (some node set is not closed under `parent`); 1: split-tree records */
     uint32_t binary_tree;      /* 1: every clade has zero or two children        */
-    uint32_t direct_table;     /* 1: 2-bit-code direct table in use (k <= 15)    */
+    uint32_t direct_table;     /* 1: 2-bit-code direct table in use (k <= 15); 2: and the index is strand-symmetric
+                                * (every k-mer shares its node set with its reverse complement: one lookup per window) */
     uint32_t n_tip_sets;       /* format 1: distinct tip lists (k-mers with the same one share a split tree) */
 } cls_db_info;
 

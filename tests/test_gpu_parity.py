@@ -223,13 +223,14 @@ def test_concurrent_host_calls_are_reentrant():
 def test_index_format_selection():
     """Which device layout / kernels an index gets."""
     cases = [
-        (SynthDb(60, 300, 8, 4), None, (1, 1, 1)),                      # closed sets, binary tree, k <= 15: fast path
+        (SynthDb(60, 300, 8, 4), None, (1, 1, 2)),                      # closed sets, binary tree, k <= 15, both strands indexed: fast path, one lookup per window
+        (SynthDb(60, 300, 8, 4), -1.0, (1, 1, 1)),                      # the same, not strand-symmetric: fast path, both strands looked up
         (SynthDb(60, 300, 17, 4), None, (1, 1, 0)),                     # k > 15: split records, murmur probe path
         (SynthDb(60, 300, 8, 4, collapse_prob=0.4), None, (1, 0, 0)),   # polytomies: split records, child walk
         (SynthDb(60, 300, 8, 4), 0.2, (0, 1, 0)),                       # a node set that is not closed: sorted lists
     ]
     for s, drop, want in cases:
-        flat = drop_random_nodes(s.flat, drop, seed=2) if drop else s.flat
+        flat = s.flat if not drop else truncate_random_sets(s.flat, 0.1, seed=2) if drop < 0 else drop_random_nodes(s.flat, drop, seed=2)
         with engine.PlacementDb(flat, device=0) as db:
             assert (db.info.format, db.info.binary_tree, db.info.direct_table) == want
 
