@@ -1,5 +1,3 @@
-timeout -k 10 800 python -m pytest tests -x -q -m gpu 2>&1 | tail -3
 B() { env $1 timeout -k 10 200 python bench.py --steps 10 --warmup 2 --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$1', d['value'], d['ms_per_step'], d['roofline']['kernel_ms'])"; }
 B A=1
-B CLS_BLOCKS_PER_CU=4
-B CLS_BLOCKS_PER_CU=6
+B A=2

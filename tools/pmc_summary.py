@@ -24,7 +24,10 @@ for k, counters in per.items():
         vals = sorted(d.values())
         big = [v for v in vals if v >= 0.5 * vals[-1]] if vals and vals[-1] > 0 else vals  # full-size launches only (bench steps)
         out[k][c] = {"per_launch_mean": sum(big) / max(1, len(big)), "launches": len(big)}
-dom = max((k for k in out if k.startswith("place_")), key=lambda k: out[k].get("FETCH_SIZE", {}).get("per_launch_mean", 0), default=None)
+# the dominant kernel = the placement kernel with the most fetched bytes over all its launches (the bench's timed
+# steps; the single statistics launch of the untimed preamble is a different template instance)
+dom = max((k for k in out if k.startswith("place_")),
+          key=lambda k: out[k].get("FETCH_SIZE", {}).get("per_launch_mean", 0) * out[k].get("FETCH_SIZE", {}).get("launches", 0), default=None)
 res = {
     "command": "rocprofv3 --pmc FETCH_SIZE | --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum (separate passes) -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline",
     "units": "FETCH_SIZE / WRITE_SIZE in KiB as rocprofv3 reports them; TCC_* in requests",

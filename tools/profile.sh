@@ -14,7 +14,15 @@ timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum -d "$OUT/p
 cd - > /dev/null
 timeout -k 10 200 $BENCH > "$OUT/bench.json" 2> "$OUT/bench.err"
 python3 tools/pmc_summary.py "$OUT" > "$OUT/pmc_summary.json"
-find "$OUT" -name "*kernel_stats.csv" -exec cp {} "$OUT/kernel_stats.csv" \;
+python3 - "$OUT" <<'PY'
+import csv, glob, re, sys
+src = glob.glob(sys.argv[1] + "/kt/*kernel_stats.csv")[0]
+with open(src, newline="") as f, open(sys.argv[1] + "/kernel_stats.csv", "w", newline="") as g:
+    w = csv.writer(g, quoting=csv.QUOTE_ALL)
+    for r in csv.reader(f):  # kernel names without their argument lists
+        r[0] = re.sub(r"\(.*$", "", r[0].replace("void ", "").replace("cls::(anonymous namespace)::", ""))[:140]
+        w.writerow(r)
+PY
 rm -rf "$OUT"/pmc_fetch/*agent_info* "$OUT"/pmc_tcc/*agent_info*
 find "$OUT" -name "*kernel_trace.csv" -delete
 find "$OUT" -name "*counter_collection.csv" -delete
