@@ -26,11 +26,12 @@
 #include "cls_host.h"
 #include "cls_host_internal.h"
 #include "cls_json.h"
+#include "cls_murmur.h"
 
-namespace {
+namespace cls_host {
 
-thread_local std::string g_err;
-int fail(int code, const std::string& m) { g_err = m; return code; }
+static thread_local std::string g_err;
+static int fail(int code, const std::string& m) { g_err = m; return code; }
 
 // ---- f64 formatting exactly as Rust's ryu (serde_json / serde_yaml floats) ------------------------
 std::string fmt_f64(double v) {
@@ -76,21 +77,7 @@ std::string fmt_f64(double v) {
     return out;
 }
 
-// ---- data model --------------------------------------------------------------------------------------
-struct Clade {
-    uint64_t id = 0;
-    bool has_parent = false;
-    uint64_t parent = 0;
-    int kind = CLS_KIND_NODE;
-    bool has_name = false, has_support = false, has_length = false, has_children = false;
-    std::string name;
-    double support = 0, length = 0;
-    std::vector<Clade> children;
-};
-
-struct Tag { std::string name; bool is_int = false; uint64_t ival = 0; std::string sval; };
-struct Annotation { uint32_t clade = 0; bool has_meta = false; std::vector<Tag> meta; };
-
+// (data model: cls_host_internal.h)
 const char* kind_name(int k) { return k == CLS_KIND_ROOT ? "ROOT" : k == CLS_KIND_LEAF ? "LEAF" : "NODE"; }
 
 Clade clade_from_json(const cls::JVal& j) {
@@ -111,24 +98,6 @@ Clade clade_from_json(const cls::JVal& j) {
     }
     return c;
 }
-
-}  // namespace
-
-struct cls_tree {
-    Clade root;
-    bool has_annotations = false;
-    std::vector<Annotation> annotations;
-    // flattened (BFS rows; children consecutive, in Clade.children order)
-    std::vector<cls_node> rows;
-    std::vector<const Clade*> row_clade;
-    std::map<uint64_t, uint32_t> first_row_of_id;  // get_node_by_id: first match in DFS order (clade.rs:95-109)
-    // k-mer map (optional)
-    bool has_kmers = false;
-    uint64_t k_size = 0, m_size = 0;
-    std::vector<uint64_t> bucket_key, bucket_kmer_off, kmer_hash, kmer_node_off, node_ids;
-};
-
-namespace {
 
 void flatten(cls_tree* t) {
     t->rows.clear(); t->row_clade.clear(); t->first_row_of_id.clear();
@@ -506,7 +475,9 @@ std::string with_extension(const std::string& path, const char* ext) {  // PathB
     return stem + "." + ext;
 }
 
-}  // namespace
+}  // namespace cls_host
+
+using namespace cls_host;
 
 extern "C" const char* cls_host_last_error(void) { return g_err.c_str(); }
 
@@ -543,50 +514,75 @@ void cls_tree_set_kmers_map(cls_tree* t, uint64_t k, uint64_t m, std::vector<uin
 
 extern "C" void cls_tree_free(cls_tree* t) { delete t; }
 
+namespace cls_host {
+void tree_from_doc(const cls::JVal& doc, cls_tree* t) {
+    const cls::JVal* root = doc.get("root");
+    t->root = clade_from_json(root ? *root : doc);  // `--only-tree` exports hold the root clade alone
+    flatten(t);
+    const cls::JVal* v;
+    if (root) {
+        t->has_header = true;
+        if ((v = doc.get("id")) && !v->is_null()) t->uuid = v->s;
+        if ((v = doc.get("name")) && !v->is_null()) t->name = v->s;
+        if ((v = doc.get("minBranchSupport")) && !v->is_null()) t->min_branch_support = v->kind == cls::JVal::Num ? v->as_f64() : strtod(v->s.c_str(), nullptr);
+        if ((v = doc.get("inMemorySize")) && !v->is_null()) { t->has_in_memory_size = true; t->in_memory_size = v->s; }
+    }
+    const cls::JVal* km = root ? doc.get("kmersMap") : nullptr;
+    if (km && !km->is_null()) {
+        t->has_kmers = true;
+        t->k_size = km->get("kSize") ? km->get("kSize")->as_u64() : 0;
+        t->m_size = km->get("mSize") ? km->get("mSize")->as_u64() : 0;
+        const cls::JVal* map = km->get("map");
+        t->bucket_kmer_off.assign(1, 0);
+        t->kmer_node_off.assign(1, 0);
+        if (map && !map->obj.empty() && map->obj.front().second.kind == cls::JVal::Arr) {
+            // files written before the minimizer buckets existed (core/src/tests/data/.../outputs/*.yaml):
+            // map = {k-mer string: [node ids]}; one bucket, keyed like mSize = 0 (kmers_map.rs:131-134)
+            t->m_size = 0;
+            t->bucket_key.push_back(0);
+            for (auto& kv : map->obj) {
+                t->kmer_hash.push_back(cls::murmur3_h1_bytes(kv.first.data(), (uint32_t)kv.first.size()));
+                for (auto& id : kv.second.arr) t->node_ids.push_back(id.as_u64());
+                t->kmer_node_off.push_back(t->node_ids.size());
+            }
+            t->bucket_kmer_off.push_back(t->kmer_hash.size());
+        } else if (map) for (auto& b : map->obj) {
+            t->bucket_key.push_back(strtoull(b.first.c_str(), nullptr, 10));
+            for (auto& kv : b.second.obj) {
+                t->kmer_hash.push_back(strtoull(kv.first.c_str(), nullptr, 10));
+                for (auto& id : kv.second.arr) t->node_ids.push_back(id.as_u64());
+                t->kmer_node_off.push_back(t->node_ids.size());
+            }
+            t->bucket_kmer_off.push_back(t->kmer_hash.size());
+        }
+    }
+    const cls::JVal* an = root ? doc.get("annotations") : nullptr;
+    if (an && an->kind == cls::JVal::Arr && !an->arr.empty()) {
+        t->has_annotations = true;
+        for (auto& a : an->arr) {
+            Annotation x;
+            x.clade = (uint32_t)a.get("clade")->as_u64();
+            if (const cls::JVal* m = a.get("meta")) if (!m->is_null()) {
+                x.has_meta = true;
+                for (auto& tg : m->arr) for (auto& kv : tg.obj) {
+                    Tag g; g.name = kv.first;
+                    if (kv.second.kind == cls::JVal::Num) { g.is_int = true; g.ival = kv.second.as_u64(); } else g.sval = kv.second.s;
+                    x.meta.push_back(g);
+                }
+            }
+            t->annotations.push_back(x);
+        }
+    }
+}
+}  // namespace cls_host
+
 extern "C" int cls_tree_load_json(const char* path, cls_tree** out) {
     if (!path || !out) return fail(CLS_E_INVALID_ARG, "cls_tree_load_json: null argument");
     try {
         std::string text = read_file(path);
         cls::JVal doc = cls::JParser(text.data(), text.size()).parse();
         auto t = std::make_unique<cls_tree>();
-        const cls::JVal* root = doc.get("root");
-        t->root = clade_from_json(root ? *root : doc);  // `--only-tree` exports hold the root clade alone
-        flatten(t.get());
-        const cls::JVal* km = root ? doc.get("kmersMap") : nullptr;
-        if (km && !km->is_null()) {
-            t->has_kmers = true;
-            t->k_size = km->get("kSize") ? km->get("kSize")->as_u64() : 0;
-            t->m_size = km->get("mSize") ? km->get("mSize")->as_u64() : 0;
-            const cls::JVal* map = km->get("map");
-            t->bucket_kmer_off.push_back(0);
-            t->kmer_node_off.push_back(0);
-            if (map) for (auto& b : map->obj) {
-                t->bucket_key.push_back(strtoull(b.first.c_str(), nullptr, 10));
-                for (auto& kv : b.second.obj) {
-                    t->kmer_hash.push_back(strtoull(kv.first.c_str(), nullptr, 10));
-                    for (auto& id : kv.second.arr) t->node_ids.push_back(id.as_u64());
-                    t->kmer_node_off.push_back(t->node_ids.size());
-                }
-                t->bucket_kmer_off.push_back(t->kmer_hash.size());
-            }
-        }
-        const cls::JVal* an = root ? doc.get("annotations") : nullptr;
-        if (an && an->kind == cls::JVal::Arr && !an->arr.empty()) {
-            t->has_annotations = true;
-            for (auto& a : an->arr) {
-                Annotation x;
-                x.clade = (uint32_t)a.get("clade")->as_u64();
-                if (const cls::JVal* m = a.get("meta")) if (!m->is_null()) {
-                    x.has_meta = true;
-                    for (auto& tg : m->arr) for (auto& kv : tg.obj) {
-                        Tag g; g.name = kv.first;
-                        if (kv.second.kind == cls::JVal::Num) { g.is_int = true; g.ival = kv.second.as_u64(); } else g.sval = kv.second.s;
-                        x.meta.push_back(g);
-                    }
-                }
-                t->annotations.push_back(x);
-            }
-        }
+        tree_from_doc(doc, t.get());
         *out = t.release();
         return CLS_OK;
     } catch (const std::exception& e) {

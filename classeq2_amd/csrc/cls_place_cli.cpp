@@ -1,9 +1,9 @@
 // cls-place: C++ look-alike of the reference's `cls place` sub-command
 // (ports/cli/src/cmds/place_sequences.rs:18-82 flag surface, :84-223 behaviour) on the GPU path.
-//   cls-place [QUERY|-] -d DB.json -o OUT [-a ANNOTATIONS.yaml] [--out-format yaml|jsonl]
+//   cls-place [QUERY|-] -d DB -o OUT [-a ANNOTATIONS.yaml] [--out-format yaml|jsonl]
 //             [-i N] [-m COV] [-r] [-f] [--device N]
-// The database is the JSON export of `cls convert database -f json` (the default .cls file is zstd-YAML,
-// for which this image has no reader).
+// The database is read like load_database does (ports/lib/src/functions/load_database.rs:9-53): the `.cls`
+// file of `cls build-db` (zstd-compressed YAML), plain YAML, or the JSON export.
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -14,10 +14,10 @@
 
 static void usage() {
     fprintf(stderr,
-            "Usage: cls-place [QUERY] --database-file-path <DB.json> --output-file-path <OUT> [OPTIONS]\n\n"
+            "Usage: cls-place [QUERY] --database-file-path <DB> --output-file-path <OUT> [OPTIONS]\n\n"
             "Arguments:\n  [QUERY]  multi-FASTA file, or \"-\" for STDIN [default: -]\n\n"
             "Options:\n"
-            "  -d, --database-file-path <PATH>     classeq database (JSON export)\n"
+            "  -d, --database-file-path <PATH>     classeq database (.cls, .cls.yaml or .cls.json)\n"
             "  -o, --output-file-path <PATH>       output file (extension replaced by .yaml / .jsonl; errors go to .error)\n"
             "  -a, --annotations-file-path <PATH>  annotations in YAML format\n"
             "      --out-format <yaml|jsonl>       [default: yaml]\n"
@@ -56,7 +56,7 @@ int main(int argc, char** argv) {
     if (fmt != "yaml" && fmt != "jsonl") { fprintf(stderr, "error: invalid value '%s' for '--out-format'\n", fmt.c_str()); return 2; }
 
     cls_tree* tree = nullptr;
-    if (cls_tree_load_json(db_path.c_str(), &tree) != CLS_OK) { fprintf(stderr, "Error loading database: %s\n", cls_host_last_error()); return 1; }
+    if (cls_tree_load(db_path.c_str(), &tree) != CLS_OK) { fprintf(stderr, "Error loading database: %s\n", cls_host_last_error()); return 1; }
     if (!ann_path.empty() && cls_tree_set_annotations_yaml(tree, ann_path.c_str()) != CLS_OK) {
         fprintf(stderr, "Error loading annotations: %s\n", cls_host_last_error());
         return 1;

@@ -27,10 +27,11 @@ EXPORTS = [
     "cls_version",
 ]
 HOST_EXPORTS = [
-    "cls_tree_load_json", "cls_tree_free", "cls_tree_set_annotations_yaml", "cls_tree_build_kmers_map", "cls_tree_desc", "cls_serialize_results",
+    "cls_tree_load_json", "cls_tree_load", "cls_tree_init_from_file", "cls_tree_from_newick", "cls_tree_serialize", "cls_tree_save", "cls_tree_free", "cls_tree_set_annotations_yaml", "cls_tree_build_kmers_map", "cls_tree_desc", "cls_serialize_results",
     "cls_host_free", "cls_place_sequences", "cls_host_last_error",
 ]
 FORMAT_YAML, FORMAT_JSONL = 0, 1
+DB_FORMAT_ZSTD, DB_FORMAT_YAML, DB_FORMAT_JSON = 0, 1, 2
 
 
 class ClsError(RuntimeError):
@@ -78,6 +79,16 @@ def lib():
         # host-side mirror (include/cls_host.h)
         L.cls_tree_load_json.argtypes = [C.c_char_p, C.POINTER(vp)]
         L.cls_tree_load_json.restype = i32
+        L.cls_tree_load.argtypes = [C.c_char_p, C.POINTER(vp)]
+        L.cls_tree_load.restype = i32
+        L.cls_tree_init_from_file.argtypes = [C.c_char_p, C.c_double, C.POINTER(vp)]
+        L.cls_tree_init_from_file.restype = i32
+        L.cls_tree_from_newick.argtypes = [C.c_char_p, C.c_char_p, C.c_double, C.POINTER(vp)]
+        L.cls_tree_from_newick.restype = i32
+        L.cls_tree_serialize.argtypes = [vp, i32, i32, C.POINTER(vp), C.POINTER(C.c_size_t)]
+        L.cls_tree_serialize.restype = i32
+        L.cls_tree_save.argtypes = [vp, C.c_char_p, i32, i32]
+        L.cls_tree_save.restype = i32
         L.cls_tree_free.argtypes = [vp]
         L.cls_tree_free.restype = None
         L.cls_tree_set_annotations_yaml.argtypes = [vp, C.c_char_p]
@@ -216,11 +227,42 @@ def _check_host(rc: int):
 class Tree:
     """cls_tree: the reference's database / tree JSON export + optional annotations (include/cls_host.h)."""
 
-    def __init__(self, json_path: str, annotations_yaml: Optional[str] = None):
+    def __init__(self, path: Optional[str] = None, annotations_yaml: Optional[str] = None, *, _handle=None):
+        """`path`: a database / tree file in any form load_database reads (.cls zstd YAML, YAML, JSON)."""
         self._h = C.c_void_p()
-        _check_host(lib().cls_tree_load_json(json_path.encode(), C.byref(self._h)))
+        if _handle is not None:
+            self._h = _handle
+        elif path.endswith(".json"):
+            _check_host(lib().cls_tree_load_json(path.encode(), C.byref(self._h)))
+        else:
+            _check_host(lib().cls_tree_load(path.encode(), C.byref(self._h)))
         if annotations_yaml:
             _check_host(lib().cls_tree_set_annotations_yaml(self._h, annotations_yaml.encode()))
+
+    @classmethod
+    def from_newick_file(cls, tree_path: str, min_branch_support: float = 70.0) -> "Tree":
+        """Tree::init_from_file: Newick -> sanitized tree (cls_tree_init_from_file)."""
+        h = C.c_void_p()
+        _check_host(lib().cls_tree_init_from_file(tree_path.encode(), min_branch_support, C.byref(h)))
+        return cls(_handle=h)
+
+    @classmethod
+    def from_newick(cls, text: str, name: Optional[str] = None, min_branch_support: float = 70.0) -> "Tree":
+        h = C.c_void_p()
+        _check_host(lib().cls_tree_from_newick(text.encode(), name.encode() if name else None, min_branch_support, C.byref(h)))
+        return cls(_handle=h)
+
+    def dumps(self, fmt: int = DB_FORMAT_YAML, only_tree: bool = False) -> bytes:
+        """`cls convert database` serialisation (cls_tree_serialize)."""
+        buf, n = C.c_void_p(), C.c_size_t()
+        _check_host(lib().cls_tree_serialize(self._h, fmt, 1 if only_tree else 0, C.byref(buf), C.byref(n)))
+        try:
+            return C.string_at(buf, n.value)
+        finally:
+            lib().cls_host_free(buf)
+
+    def save(self, path: str, fmt: int = DB_FORMAT_ZSTD, only_tree: bool = False) -> None:
+        _check_host(lib().cls_tree_save(self._h, path.encode(), fmt, 1 if only_tree else 0))
 
     def close(self):
         if getattr(self, "_h", None):

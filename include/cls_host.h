@@ -26,6 +26,25 @@ enum { CLS_FORMAT_YAML = 0, CLS_FORMAT_JSONL = 1 }; /* OutputFormat, core/src/do
  * (ports/lib/src/functions/load_database.rs:9-53) for the JSON form. */
 int cls_tree_load_json(const char* path, cls_tree** out);
 void cls_tree_free(cls_tree* t);
+/* Tree::init_from_file (core/src/domain/dtos/tree.rs:164-230): parse a rooted Newick tree (.nwk/.newick/.tree),
+ * node ids = pre-order of the text (what the phylotree arena yields), internal labels = support values, then
+ * sanitize (tree.rs:252-291: a clade whose support is below `min_branch_support` hands its children to its
+ * parent) and fix_parent_ids.  Tree.name = the file name, Tree.id = UUID v3 (DNS namespace) of it. */
+int cls_tree_init_from_file(const char* tree_path, double min_branch_support, cls_tree** out);
+/* The same from text already in memory (`tree_name` NULL: "UnnamedTree"). */
+int cls_tree_from_newick(const char* newick_text, const char* tree_name, double min_branch_support, cls_tree** out);
+/* load_database (ports/lib/src/functions/load_database.rs:9-53): a `.cls` file (zstd-compressed YAML, needs the
+ * system's libzstd.so.1 at run time), plain YAML, or the JSON export; a whole database or an `--only-tree` file;
+ * also the k-mer-keyed map of databases written before the minimizer buckets existed. */
+int cls_tree_load(const char* path, cls_tree** out);
+/* `cls convert database -f {zstd|yaml|json} [--only-tree]` (ports/cli/src/cmds/convert.rs:161-205) and the file
+ * `cls build-db` writes (ports/cli/src/cmds/build_db.rs:70-76): serde_yaml / serde_json::to_writer_pretty of the
+ * Tree (or of its root clade).  cls_tree_save forces the reference's extensions (.cls / .cls.yaml / .cls.json). */
+#define CLS_DB_FORMAT_ZSTD 0
+#define CLS_DB_FORMAT_YAML 1
+#define CLS_DB_FORMAT_JSON 2
+int cls_tree_serialize(const cls_tree* t, int format, int only_tree, char** out, size_t* out_len); /* cls_host_free(*out) */
+int cls_tree_save(const cls_tree* t, const char* path, int format, int only_tree);
 /* `-a/--annotations-file-path` of `cls place` (ports/cli/src/cmds/place_sequences.rs:137-144). */
 int cls_tree_set_annotations_yaml(cls_tree* t, const char* path);
 /* `cls build-db` on an already parsed tree: map_kmers_to_tree (core/src/use_cases/build_database/mod.rs:26-181).

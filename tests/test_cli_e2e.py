@@ -72,6 +72,9 @@ def test_cli_places_bundled_fixture(tmp_path, fmt):
     headers = [str(h) for h in np.load(os.path.join(ROOT, "tests", "golden", "colletotrichum_k12.npz"))["headers"]]
     db, fa, out = str(tmp_path / "db.json"), str(tmp_path / "q.fasta"), str(tmp_path / "res" / "result.out")
     write_db_json(flat, db)
+    if fmt == "jsonl":  # the form `cls build-db` writes: zstd-compressed YAML
+        engine.Tree(db).save(str(tmp_path / "db"), engine.DB_FORMAT_ZSTD)
+        db = str(tmp_path / "db.cls")
     write_fasta(fa, headers, bases, offsets)
     cmd = [CLI, fa, "-d", db, "-o", out, "--out-format", fmt]
     r = subprocess.run(cmd, capture_output=True, text=True)
