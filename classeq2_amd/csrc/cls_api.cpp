@@ -73,6 +73,7 @@ struct cls_db {
 };
 
 extern "C" const char* cls_last_error(void) { return g_err.c_str(); }
+extern "C" void cls_internal_set_error(const char* msg) { g_err = msg ? msg : ""; }  // for the library's other translation units
 
 extern "C" const char* cls_version(void) { return "classeq2_amd 0.1.0 gfx950 abi1"; }
 
@@ -385,4 +386,84 @@ extern "C" int cls_place_batch_stats(cls_db* db, const char* bases, const uint64
                                      const cls_params* params, cls_placement* out, cls_query_stats* stats) {
     if (!stats) return fail(CLS_E_INVALID_ARG, "cls_place_batch_stats: stats is null");
     return place_host(db, bases, offsets, n, params, out, stats);
+}
+
+// FASTA text -> records, all on the device: H2D of the file bytes, cls_fasta_scan_device(), placement straight
+// from the scanned bases, D2H of the 24-byte records and of the headers (the output stage needs those on the
+// host).  `fa->bases` / `fa->base_off` come back NULL: the bases never leave the device.
+extern "C" int cls_place_fasta_text(cls_db* db, const char* text, size_t len, const cls_params* params, cls_fasta* fa,
+                                    cls_placement** records) {
+    if (!db || !fa || !records || (!text && len)) return fail(CLS_E_INVALID_ARG, "cls_place_fasta_text: null argument");
+    memset(fa, 0, sizeof *fa);
+    *records = nullptr;
+    int prev = 0;
+    CLS_HIP(hipGetDevice(&prev));
+    CLS_HIP(hipSetDevice(db->device));
+    hipStream_t stream = nullptr;
+    void *d_text = nullptr, *d_out = nullptr;
+    cls_fasta_dev dv;
+    memset(&dv, 0, sizeof dv);
+    cls_placement* recs = nullptr;
+    bool ok = false;
+    auto cleanup = [&]() {
+        if (d_text) (void)hipFree(d_text);
+        if (d_out) (void)hipFree(d_out);
+        cls_fasta_dev_free(&dv);
+        if (stream) (void)hipStreamDestroy(stream);
+        (void)hipSetDevice(prev);
+        if (!ok) { free(recs); cls_fasta_free(fa); }
+    };
+#define CLS_TRY(expr)                                                                                     \
+    do {                                                                                                  \
+        hipError_t e_ = (expr);                                                                           \
+        if (e_ != hipSuccess) { cleanup(); return fail(e_ == hipErrorOutOfMemory ? CLS_E_NOMEM : CLS_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); } \
+    } while (0)
+    try {
+        CLS_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+        CLS_TRY(hipMalloc(&d_text, len ? len : 16));
+        if (len) CLS_TRY(hipMemcpyAsync(d_text, text, len, hipMemcpyHostToDevice, stream));
+        int rc = cls_fasta_scan_device(d_text, len, &dv, stream);
+        if (rc != CLS_OK) { cleanup(); return rc; }
+        (void)hipFree(d_text);
+        d_text = nullptr;
+        const uint32_t n = dv.n;
+        fa->n = n;
+        fa->truncated = dv.truncated;
+        fa->headers = (char*)malloc(dv.n_header_bytes + 1);
+        fa->header_off = (uint64_t*)malloc(((size_t)n + 1) * 8);
+        recs = (cls_placement*)malloc(((size_t)n + 1) * sizeof(cls_placement));
+        std::vector<uint64_t> boff((size_t)n + 1);
+        if (!fa->headers || !fa->header_off || !recs) { cleanup(); return fail(CLS_E_NOMEM, "cls_place_fasta_text: out of host memory"); }
+        if (dv.n_header_bytes) CLS_TRY(hipMemcpyAsync(fa->headers, dv.d_headers, dv.n_header_bytes, hipMemcpyDeviceToHost, stream));
+        CLS_TRY(hipMemcpyAsync(fa->header_off, dv.d_header_off, ((size_t)n + 1) * 8, hipMemcpyDeviceToHost, stream));
+        CLS_TRY(hipMemcpyAsync(boff.data(), dv.d_base_off, ((size_t)n + 1) * 8, hipMemcpyDeviceToHost, stream));
+        CLS_TRY(hipStreamSynchronize(stream));
+        const uint32_t max_reads = 16u << 20;  // bounds the per-call scratch (class lists, sort keys)
+        if (n) CLS_TRY(hipMalloc(&d_out, (size_t)std::min(n, max_reads) * sizeof(cls_placement)));
+        for (uint32_t first = 0; first < n; first += max_reads) {
+            const uint32_t cnt = std::min(max_reads, n - first);
+            uint64_t longest = 0;
+            uint32_t n_long = 0;
+            for (uint32_t i = 0; i < cnt; ++i) {
+                const uint64_t l = boff[first + i + 1] - boff[first + i];
+                const uint64_t nk = l < db->dev.k ? 0 : 2 * (l - db->dev.k + 1);
+                if (nk > cls::MAX_READ_KMERS) { ++n_long; longest = std::max(longest, std::min(l, HARD_MAX_READ_LEN)); }
+            }
+            rc = place_device(db, dv.d_bases, (const uint64_t*)dv.d_base_off + first, cnt, params, d_out, nullptr, stream, (uint32_t)(2 * longest), n_long);
+            if (rc != CLS_OK) { cleanup(); return rc; }
+            CLS_TRY(hipMemcpyAsync(recs + first, d_out, (size_t)cnt * sizeof(cls_placement), hipMemcpyDeviceToHost, stream));
+            CLS_TRY(hipStreamSynchronize(stream));
+        }
+        *records = recs;
+        ok = true;
+        cleanup();
+        return CLS_OK;
+    } catch (const std::bad_alloc&) {
+        cleanup();
+        return fail(CLS_E_NOMEM, "cls_place_fasta_text: out of host memory");
+    } catch (...) {
+        cleanup();
+        return fail(CLS_E_INTERNAL, "cls_place_fasta_text: unknown exception");
+    }
+#undef CLS_TRY
 }

@@ -677,14 +677,14 @@ extern "C" int cls_place_sequences(cls_db* db, const cls_tree* t, const char* qu
         else text = read_file(query_path);
         auto t0 = std::chrono::steady_clock::now();
         cls_fasta fa;
-        int rc = cls_fasta_parse(text.data(), text.size(), &fa);
-        if (rc != CLS_OK) { fclose(fo); fclose(fe); return fail(rc, "cls_fasta_parse failed"); }
-        std::vector<cls_placement> recs(fa.n);
-        rc = cls_place_batch(db, fa.bases, fa.base_off, fa.n, params, recs.data());
-        if (rc != CLS_OK) { std::string m = cls_last_error(); cls_fasta_free(&fa); fclose(fo); fclose(fe); return fail(rc, m); }
+        cls_placement* recs = nullptr;  // FASTA stage + placement on the device; headers + records come back
+        int rc = cls_place_fasta_text(db, text.data(), text.size(), params, &fa, &recs);
+        if (rc != CLS_OK) { std::string m = cls_last_error(); fclose(fo); fclose(fe); return fail(rc, m); }
+        std::string().swap(text);
         char *ot = nullptr, *et = nullptr;
         size_t ol = 0, el = 0;
-        rc = cls_serialize_results(t, fa.headers, fa.header_off, fa.n, recs.data(), format, &ot, &ol, &et, &el);
+        rc = cls_serialize_results(t, fa.headers, fa.header_off, fa.n, recs, format, &ot, &ol, &et, &el);
+        free(recs);
         if (rc == CLS_OK) {
             if (ol && fwrite(ot, 1, ol, fo) != ol) rc = fail(CLS_E_INTERNAL, "Error writing to file");
             if (el && fwrite(et, 1, el, fe) != el) rc = fail(CLS_E_INTERNAL, "Error writing to file");

@@ -23,7 +23,8 @@ _LIB = None
 EXPORTS = [
     "cls_device_count", "cls_db_create", "cls_db_validate", "cls_db_destroy", "cls_db_info_get", "cls_db_kernel_time",
     "cls_db_set_max_read_len", "cls_place_batch",
-    "cls_place_batch_device", "cls_place_batch_stats", "cls_fasta_parse", "cls_fasta_free", "cls_last_error",
+    "cls_place_batch_device", "cls_place_batch_stats", "cls_fasta_parse", "cls_fasta_free", "cls_fasta_scan_device", "cls_fasta_dev_free",
+    "cls_fasta_parse_gpu", "cls_place_fasta_text", "cls_last_error",
     "cls_version",
 ]
 HOST_EXPORTS = [
@@ -72,6 +73,10 @@ def lib():
         L.cls_place_batch_device.restype = i32
         L.cls_fasta_parse.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(_abi.Fasta)]
         L.cls_fasta_parse.restype = i32
+        L.cls_fasta_parse_gpu.argtypes = [C.c_char_p, C.c_size_t, i32, C.POINTER(_abi.Fasta)]
+        L.cls_fasta_parse_gpu.restype = i32
+        L.cls_place_fasta_text.argtypes = [vp, C.c_char_p, C.c_size_t, C.POINTER(_abi.Params), C.POINTER(_abi.Fasta), C.POINTER(vp)]
+        L.cls_place_fasta_text.restype = i32
         L.cls_fasta_free.argtypes = [C.POINTER(_abi.Fasta)]
         L.cls_fasta_free.restype = None
         L.cls_last_error.restype = C.c_char_p
@@ -140,10 +145,14 @@ def validate(flat: FlatDb) -> None:
     _check(lib().cls_db_validate(C.byref(d)))
 
 
-def fasta_parse(text: bytes):
-    """-> (headers: list[bytes], bases u8[], offsets u64[n+1], truncated: bool); a1 semantics."""
+def fasta_parse(text: bytes, device: Optional[int] = None):
+    """-> (headers: list[bytes], bases u8[], offsets u64[n+1], truncated: bool); a1 semantics.
+    `device`: run the stage's data-parallel passes on that GPU (cls_fasta_parse_gpu) instead of the host parser."""
     f = _abi.Fasta()
-    _check(lib().cls_fasta_parse(text, len(text), C.byref(f)))
+    if device is None:
+        _check(lib().cls_fasta_parse(text, len(text), C.byref(f)))
+    else:
+        _check(lib().cls_fasta_parse_gpu(text, len(text), device, C.byref(f)))
     try:
         n = f.n
         hoff = np.ctypeslib.as_array(f.header_off, shape=(n + 1,)).copy()
@@ -205,6 +214,24 @@ class PlacementDb:
         ms, cnt = C.c_double(0), C.c_uint64(0)
         _check(lib().cls_db_kernel_time(self._h, C.byref(ms), C.byref(cnt), 1 if reset else 0))
         return ms.value, cnt.value
+
+    def place_fasta_text(self, text: bytes, params: Optional[_abi.Params] = None):
+        """FASTA text -> (headers, records, truncated) with the FASTA stage and the placement on the device
+        (cls_place_fasta_text): the reads never return to the host."""
+        f = _abi.Fasta()
+        recs = C.c_void_p()
+        pp = C.byref(params) if params is not None else None
+        _check(lib().cls_place_fasta_text(self._h, text, len(text), pp, C.byref(f), C.byref(recs)))
+        try:
+            n = f.n
+            hoff = np.ctypeslib.as_array(f.header_off, shape=(n + 1,)).copy()
+            hraw = C.string_at(f.headers, int(hoff[-1]))
+            headers = [hraw[int(hoff[i]) : int(hoff[i + 1])] for i in range(n)]
+            out = np.frombuffer(C.string_at(recs, n * 24), dtype=_abi.PLACEMENT_DTYPE).copy() if n else np.zeros(0, _abi.PLACEMENT_DTYPE)
+            return headers, out, bool(f.truncated)
+        finally:
+            lib().cls_fasta_free(C.byref(f))
+            lib().cls_host_free(recs)
 
     def set_max_read_len(self, n_bases: int) -> None:
         """Longest read place_batch_device() provisions for (cls_db_set_max_read_len)."""

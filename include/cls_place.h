@@ -233,6 +233,31 @@ typedef struct cls_fasta {
 int cls_fasta_parse(const char* text, size_t len, cls_fasta* out);
 void cls_fasta_free(cls_fasta* f);
 
+/* The same stage as data-parallel passes on the device: `d_text` = the file's bytes in HBM; the filtered bases
+ * and their offsets stay in HBM, ready for cls_place_batch_device() (the reads never return to the host); the
+ * headers are only needed by the output stage.  Synchronises `hip_stream` (the sizes of the outputs depend on
+ * the text).  Buffers hold at least n_bases / n_header_bytes bytes and n + 1 offsets. */
+typedef struct cls_fasta_dev {
+    uint32_t n;
+    uint32_t truncated;
+    void* d_headers;          /* concatenated header bytes                      */
+    void* d_header_off;       /* uint64 [n+1]                                   */
+    void* d_bases;            /* concatenated filtered (upper-case ACGT) bases  */
+    void* d_base_off;         /* uint64 [n+1]                                   */
+    uint64_t n_header_bytes;
+    uint64_t n_bases;
+} cls_fasta_dev;
+int cls_fasta_scan_device(const void* d_text, uint64_t len, cls_fasta_dev* out, void* hip_stream);
+void cls_fasta_dev_free(cls_fasta_dev* f);
+/* Host text in, host records out, through the device passes on `device` (-1: current). */
+int cls_fasta_parse_gpu(const char* text, size_t len, int device, cls_fasta* out);
+/* FASTA text -> placement records without the reads ever returning to the host: H2D of the file, the device
+ * FASTA stage, cls_place_batch_device() on its output, D2H of the records (`*records`, free() it) and of the
+ * headers (`fa`: n, truncated, headers, header_off; its bases / base_off stay NULL; cls_fasta_free() it).
+ * Replaces mod.rs:108-159 (reader thread + channel + per-query place_sequence). */
+int cls_place_fasta_text(cls_db* db, const char* text, size_t len, const cls_params* params, cls_fasta* fa,
+                         cls_placement** records);
+
 /* Thread-local message of the last failing call on this thread ("" if none). */
 const char* cls_last_error(void);
 
