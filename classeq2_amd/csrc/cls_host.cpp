@@ -21,6 +21,7 @@
 #include <set>
 #include <sstream>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "cls_host.h"
@@ -461,11 +462,19 @@ void serialize_one(const cls_tree* t, const std::string& header, const cls_place
 }
 
 std::string read_file(const char* path) {
-    std::ifstream f(path, std::ios::binary);
+    FILE* f = fopen(path, "rb");
     if (!f) throw std::runtime_error(std::string("cannot open ") + path + ": " + strerror(errno));
-    std::stringstream ss;
-    ss << f.rdbuf();
-    return ss.str();
+    std::string s;
+    struct stat sb;
+    if (fstat(fileno(f), &sb) == 0 && S_ISREG(sb.st_mode) && sb.st_size > 0) {  // regular file: one read into place
+        s.resize((size_t)sb.st_size);
+        const size_t got = fread(&s[0], 1, s.size(), f);
+        s.resize(got);
+    }
+    char buf[1 << 16];  // pipes, files that grew, ...
+    for (size_t got; (got = fread(buf, 1, sizeof buf, f)) > 0;) s.append(buf, got);
+    fclose(f);
+    return s;
 }
 
 std::string with_extension(const std::string& path, const char* ext) {  // PathBuf::set_extension
@@ -630,19 +639,40 @@ extern "C" int cls_serialize_results(const cls_tree* t, const char* headers, con
                                      char** err_text, size_t* err_len) {
     if (!t || !header_off || (!recs && n) || !out_text || !out_len) return fail(CLS_E_INVALID_ARG, "cls_serialize_results: null argument");
     try {
-        std::string o, e;
-        for (uint32_t i = 0; i < n; ++i) {
-            const std::string header(headers + header_off[i], headers + header_off[i + 1]);
-            if (const char* et = error_text(recs[i].status)) { e += et; continue; }  // mod.rs:160-169: appended without a newline
-            serialize_one(t, header, recs[i], format, o);
+        // records are independent: contiguous slices on the host's threads, concatenated in input order
+        unsigned nt = std::max(1u, std::min(64u, std::thread::hardware_concurrency()));
+        if (n < 4096) nt = 1;
+        std::vector<std::string> o(nt), e(nt);
+        std::vector<std::string> errs(nt);
+        auto work = [&](unsigned w) {
+            try {
+                const uint32_t lo = (uint32_t)((uint64_t)n * w / nt), hi = (uint32_t)((uint64_t)n * (w + 1) / nt);
+                o[w].reserve((size_t)(hi - lo) * 320);
+                for (uint32_t i = lo; i < hi; ++i) {
+                    const std::string header(headers + header_off[i], headers + header_off[i + 1]);
+                    if (const char* et = error_text(recs[i].status)) { e[w] += et; continue; }  // mod.rs:160-169: appended without a newline
+                    serialize_one(t, header, recs[i], format, o[w]);
+                }
+            } catch (const std::exception& ex) { errs[w] = ex.what(); if (errs[w].empty()) errs[w] = "error"; }
+        };
+        if (nt == 1) work(0);
+        else {
+            std::vector<std::thread> th;
+            for (unsigned w = 0; w < nt; ++w) th.emplace_back(work, w);
+            for (auto& x : th) x.join();
         }
-        *out_text = (char*)malloc(o.size() + 1);
+        for (auto& m : errs) if (!m.empty()) return fail(CLS_E_INTERNAL, "cls_serialize_results: " + m);
+        size_t ol = 0, el = 0;
+        for (unsigned w = 0; w < nt; ++w) { ol += o[w].size(); el += e[w].size(); }
+        *out_text = (char*)malloc(ol + 1);
         if (!*out_text) return fail(CLS_E_NOMEM, "cls_serialize_results: out of memory");
-        memcpy(*out_text, o.data(), o.size()); (*out_text)[o.size()] = 0; *out_len = o.size();
+        { size_t p = 0; for (unsigned w = 0; w < nt; ++w) { memcpy(*out_text + p, o[w].data(), o[w].size()); p += o[w].size(); } }
+        (*out_text)[ol] = 0; *out_len = ol;
         if (err_text && err_len) {
-            *err_text = (char*)malloc(e.size() + 1);
+            *err_text = (char*)malloc(el + 1);
             if (!*err_text) { free(*out_text); return fail(CLS_E_NOMEM, "cls_serialize_results: out of memory"); }
-            memcpy(*err_text, e.data(), e.size()); (*err_text)[e.size()] = 0; *err_len = e.size();
+            { size_t p = 0; for (unsigned w = 0; w < nt; ++w) { memcpy(*err_text + p, e[w].data(), e[w].size()); p += e[w].size(); } }
+            (*err_text)[el] = 0; *err_len = el;
         }
         return CLS_OK;
     } catch (const std::exception& ex) {
@@ -672,19 +702,23 @@ extern "C" int cls_place_sequences(cls_db* db, const cls_tree* t, const char* qu
         FILE* fe = fopen(err_path.c_str(), "ab");
         if (!fo || !fe) { if (fo) fclose(fo); if (fe) fclose(fe); return fail(CLS_E_INVALID_ARG, "Unable to open file"); }
         // ---- read the WHOLE input first (mod.rs:118-119), then place, then write ---------------------------
+        auto t0 = std::chrono::steady_clock::now();  // the reference's UCPLACE0001 -> UCPLACE0002 window (mod.rs:64-67, 264-267): read + place + write
         std::string text;
         if (strcmp(query_path, "-") == 0) { std::stringstream ss; ss << std::cin.rdbuf(); text = ss.str(); }
         else text = read_file(query_path);
-        auto t0 = std::chrono::steady_clock::now();
         cls_fasta fa;
         cls_placement* recs = nullptr;  // FASTA stage + placement on the device; headers + records come back
+        auto t1 = std::chrono::steady_clock::now();
         int rc = cls_place_fasta_text(db, text.data(), text.size(), params, &fa, &recs);
         if (rc != CLS_OK) { std::string m = cls_last_error(); fclose(fo); fclose(fe); return fail(rc, m); }
         std::string().swap(text);
+        const bool timing = getenv("CLS_TIMING") != nullptr;
+        auto t2 = std::chrono::steady_clock::now();
         char *ot = nullptr, *et = nullptr;
         size_t ol = 0, el = 0;
         rc = cls_serialize_results(t, fa.headers, fa.header_off, fa.n, recs, format, &ot, &ol, &et, &el);
         free(recs);
+        auto t3 = std::chrono::steady_clock::now();
         if (rc == CLS_OK) {
             if (ol && fwrite(ot, 1, ol, fo) != ol) rc = fail(CLS_E_INTERNAL, "Error writing to file");
             if (el && fwrite(et, 1, el, fe) != el) rc = fail(CLS_E_INTERNAL, "Error writing to file");
@@ -693,7 +727,12 @@ extern "C" int cls_place_sequences(cls_db* db, const cls_tree* t, const char* qu
         if (n_placed) *n_placed = fa.n;
         cls_fasta_free(&fa);
         fclose(fo); fclose(fe);
-        if (seconds) *seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        auto t4 = std::chrono::steady_clock::now();
+        if (seconds) *seconds = std::chrono::duration<double>(t4 - t0).count();
+        if (timing) {
+            auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+            fprintf(stderr, "cls_place_sequences: read %.1f ms, fasta+place %.1f ms, serialise %.1f ms, write %.1f ms\n", ms(t0, t1), ms(t1, t2), ms(t2, t3), ms(t3, t4));
+        }
         return rc;
     } catch (const std::exception& ex) {
         return fail(CLS_E_INTERNAL, std::string("cls_place_sequences: ") + ex.what());
