@@ -135,6 +135,17 @@ class Fasta(C.Structure):
     ]
 
 
+class ServiceStats(C.Structure):
+    _fields_ = [
+        ("jobs_submitted", C.c_uint64),
+        ("jobs_done", C.c_uint64),
+        ("reads_placed", C.c_uint64),
+        ("device_batches", C.c_uint64),
+        ("max_jobs_in_batch", C.c_uint64),
+        ("models", C.c_uint64),
+    ]
+
+
 class SynthCfg(C.Structure):
     _fields_ = [
         ("n_leaves", C.c_uint32),

@@ -31,6 +31,9 @@ HOST_EXPORTS = [
     "cls_tree_load_json", "cls_tree_load", "cls_tree_init_from_file", "cls_tree_from_newick", "cls_tree_serialize", "cls_tree_save", "cls_tree_free", "cls_tree_set_annotations_yaml", "cls_tree_build_kmers_map", "cls_tree_desc", "cls_serialize_results",
     "cls_host_free", "cls_place_sequences", "cls_host_last_error",
 ]
+SERVICE_EXPORTS = [
+    "cls_service_create", "cls_service_destroy", "cls_service_add_model", "cls_service_submit", "cls_service_wait", "cls_service_stats_get",
+]
 FORMAT_YAML, FORMAT_JSONL = 0, 1
 DB_FORMAT_ZSTD, DB_FORMAT_YAML, DB_FORMAT_JSON = 0, 1, 2
 
@@ -111,6 +114,19 @@ def lib():
                                           C.POINTER(u32), C.POINTER(C.c_double)]
         L.cls_place_sequences.restype = i32
         L.cls_host_last_error.restype = C.c_char_p
+        # resident batching service (include/cls_service.h)
+        L.cls_service_create.argtypes = [C.POINTER(vp)]
+        L.cls_service_create.restype = i32
+        L.cls_service_destroy.argtypes = [vp]
+        L.cls_service_destroy.restype = None
+        L.cls_service_add_model.argtypes = [vp, C.c_char_p, vp]
+        L.cls_service_add_model.restype = i32
+        L.cls_service_submit.argtypes = [vp, C.c_char_p, C.c_char_p, C.c_size_t, C.POINTER(_abi.Params), C.POINTER(C.c_uint64)]
+        L.cls_service_submit.restype = i32
+        L.cls_service_wait.argtypes = [vp, C.c_uint64, C.POINTER(_abi.Fasta), C.POINTER(vp)]
+        L.cls_service_wait.restype = i32
+        L.cls_service_stats_get.argtypes = [vp, C.POINTER(_abi.ServiceStats)]
+        L.cls_service_stats_get.restype = i32
         _LIB = L
     return _LIB
 
@@ -337,3 +353,60 @@ def place_sequences(db: "PlacementDb", tree: Tree, query_path: str, out_file: st
                                           C.byref(params) if params is not None else None, 1 if overwrite else 0, fmt,
                                           C.byref(n), C.byref(sec)))
     return n.value, sec.value
+
+
+class Service:
+    """Resident batching service (include/cls_service.h): models stay on the device, waiting jobs share batches."""
+
+    def __init__(self):
+        self._h = C.c_void_p()
+        _check(lib().cls_service_create(C.byref(self._h)))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().cls_service_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def add_model(self, model_id: str, db: "PlacementDb") -> None:
+        """The service takes the handle over (`db` must not be used or closed afterwards)."""
+        _check(lib().cls_service_add_model(self._h, model_id.encode(), db._h))
+        db._h = C.c_void_p()
+
+    def submit(self, model_id: str, fasta_text: bytes, params: Optional[_abi.Params] = None) -> int:
+        t = C.c_uint64(0)
+        _check(lib().cls_service_submit(self._h, model_id.encode(), fasta_text, len(fasta_text),
+                                        C.byref(params) if params is not None else None, C.byref(t)))
+        return t.value
+
+    def wait(self, ticket: int):
+        """-> (headers, records, truncated) of the job."""
+        f = _abi.Fasta()
+        recs = C.c_void_p()
+        _check(lib().cls_service_wait(self._h, ticket, C.byref(f), C.byref(recs)))
+        try:
+            n = f.n
+            hoff = np.ctypeslib.as_array(f.header_off, shape=(n + 1,)).copy()
+            hraw = C.string_at(f.headers, int(hoff[-1]))
+            headers = [hraw[int(hoff[i]) : int(hoff[i + 1])] for i in range(n)]
+            out = np.frombuffer(C.string_at(recs, n * 24), dtype=_abi.PLACEMENT_DTYPE).copy() if n else np.zeros(0, _abi.PLACEMENT_DTYPE)
+            return headers, out, bool(f.truncated)
+        finally:
+            lib().cls_fasta_free(C.byref(f))
+            lib().cls_host_free(recs)
+
+    def stats(self) -> dict:
+        st = _abi.ServiceStats()
+        _check(lib().cls_service_stats_get(self._h, C.byref(st)))
+        return {k: int(getattr(st, k)) for k, _ in _abi.ServiceStats._fields_}

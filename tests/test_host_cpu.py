@@ -18,7 +18,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def test_header_symbols_exported():
     L = engine.lib()
-    for header, exports in (("cls_place.h", engine.EXPORTS), ("cls_host.h", engine.HOST_EXPORTS)):
+    for header, exports in (("cls_place.h", engine.EXPORTS), ("cls_host.h", engine.HOST_EXPORTS), ("cls_service.h", engine.SERVICE_EXPORTS)):
         hdr = open(os.path.join(ROOT, "include", header)).read()
         declared = set(re.findall(r"^(?:int|void|const char\*)\s+(cls_[a-z0-9_]+)\(", hdr, flags=re.M))
         assert declared == set(exports), (header, declared ^ set(exports))
