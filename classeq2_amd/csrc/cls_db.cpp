@@ -379,7 +379,7 @@ int encode_db(const cls_db_desc* d, EncodedDb& E, std::string& err) {
         E.table[i] = Slot{h, (off << LOC_BUCKET_BITS) | bucket_of[j]};
     }
     // ---- 6. direct table for small k -----------------------------------------------------
-    if (E.format == FMT_SPLIT && E.strictly_binary && d->k_size <= DIRECT_MAX_K && N < DIRECT_TIP_MASK) {
+    if (E.format == FMT_SPLIT && d->k_size <= DIRECT_MAX_K && N < DIRECT_TIP_MASK) {
         const uint32_t K = (uint32_t)d->k_size, M = (uint32_t)std::min<uint64_t>(d->m_size, d->k_size);
         const uint64_t n_codes = 1ULL << (2 * K);
         E.direct.assign(4 * n_codes, 0);  // {record offset, root split, first tip | bit length << 27, last tip | has_root << 31}

@@ -69,7 +69,7 @@ constexpr uint32_t POST_HEADER_WORDS = 2;
 constexpr uint32_t SPLIT_HEADER_RECS = 2;
 constexpr uint32_t SPLIT_FIRST_REC = 2;
 
-// ---- direct k-mer table (k <= DIRECT_MAX_K, FMT_SPLIT, binary tree) ------------------------
+// ---- direct k-mer table (k <= DIRECT_MAX_K, FMT_SPLIT) ---------------------------------------
 // For small k every possible k-mer is enumerated once at cls_db_create(): its 2-bit
 // code (A=0 C=1 T=2 G=3 = (ascii >> 1) & 3, first base in the low bits) indexes a table
 // of 16-byte entries that hold the k-mer's whole initial descent state, so the query

@@ -944,7 +944,11 @@ struct FastCtx {
     uint32_t* gkey;    // LDS: tip-set groups of the read's k-mers: key (root split, or the single tip) ...
     uint32_t* gcnt;    // ... and how many distinct k-mers carry it
     uint4* stage;      // LDS: the groups compacted {first tip, last tip, split, weight}; lies over set/gkey/gcnt
+    uint32_t* ccnt;    // LDS (polytomy trees): k-mers under each non-LEAF child of the current clade ...
+    uint32_t* conly;   // ... and those under no other one
+    uint32_t* cpre;    // ... and where each child's pre-order interval starts (+ the end of the last one)
 };
+constexpr uint32_t FAST_MAX_ARITY = 256;  // non-LEAF children per clade the fast path keeps counters for
 
 // Front of the fast path, shared with order_key_kernel: the read -> LDS (upper-cased, validated),
 // 2 bits per base, then per query k-mer its 2-bit code and the direct-table entry
@@ -1016,7 +1020,7 @@ __device__ __forceinline__ bool fast_front(const DbDev& db, const FastCtx& cx, c
     return true;
 }
 
-template <int SLOTS, int SET_BITS, bool STATS, bool ADDR32, bool CANON>
+template <int SLOTS, int SET_BITS, bool STATS, bool ADDR32, bool CANON, bool POLY>
 __device__ __forceinline__ void place_read_fast(const DbDev& db, const PlaceParams& prm, const FastCtx& cx,
                                                 const uint8_t* __restrict__ bases, uint64_t b0, uint64_t b1, uint32_t r,
                                                 cls_placement* __restrict__ out, cls_query_stats* __restrict__ stats,
@@ -1145,6 +1149,97 @@ __device__ __forceinline__ void place_read_fast(const DbDev& db, const PlacePara
         ++iteration;
         if (iteration > prm.max_iterations) { write_record(out, r, CLS_ERR_MAX_ITER, 0, 0, (uint32_t)iteration, 0); return; }
         const uint32_t fc = P.s[2], m = P.s[3];
+        if (POLY && (P.s[7] >> 8) != 2) {
+            // ---- a clade that does not have exactly two children (polytomy after support collapse) -----------------
+            // The Cartesian tree breaks ties to the left, so the splits between a group's occupied children form a
+            // right-going chain: every group walks ITS OWN chain (child under its first tip by binary search over the
+            // children's intervals, then one 8-byte read per further occupied child), adding its weight to the
+            // per-child counters in LDS.  Cost per group = children it has tips under, whatever the clade's arity.
+            const DNode* __restrict__ nodes = db.nodes;
+            uint32_t last_end = 0;
+            if (m) { const snode_t Lc = load_node(nodes, fc + m - 1); last_end = Lc.s[0] + Lc.s[1]; }  // the non-LEAF children come first
+            for (uint32_t i = lane; i < m; i += 64) { cx.ccnt[i] = 0; cx.conly[i] = 0; cx.cpre[i] = nodes[fc + i].pre; }  // children tile [pre+1, last_end)
+            if (lane == 0) cx.cpre[m] = last_end;
+            wave_sync();
+            uint32_t u_lane = 0;
+            auto walk = [&](uint32_t v, uint32_t vh, uint32_t xx, uint32_t w) {
+                uint32_t nin = 0, which = 0;
+                while (v < last_end) {  // v lies under exactly one non-LEAF child: the last one that starts at or before it
+                    uint32_t lo_ = 0, hi_ = m;
+                    while (hi_ - lo_ > 1) { const uint32_t mid = (lo_ + hi_) >> 1; if (cx.cpre[mid] <= v) lo_ = mid; else hi_ = mid; }
+                    const uint32_t c_end = cx.cpre[lo_ + 1];  // (back to back: the next child starts where this one ends)
+                    atomicAdd(&cx.ccnt[lo_], w);
+                    if (nin == 0) which = lo_;
+                    if (nin < 2) ++nin;
+                    if (vh < c_end) break;                                         // no tip beyond this child
+                    const uint2 t = ldx<uint2, ADDR32>(half, 2 * xx + 1);          // first tip beyond it, the split of the rest
+                    v = t.x; xx = t.y;
+                }
+                if (nin == 1) atomicAdd(&cx.conly[which], w);
+                u_lane += nin ? w : 0u;
+            };
+            walk(vlo, vhi, x, wt);
+#pragma unroll 1
+            for (uint32_t c = 1; c < n_chunks; ++c) { const uint4 g = cx.stage[c * 64 + lane]; walk(g.x, g.y, g.z, g.w); }
+            const uint32_t U = wave_sum(u_lane);
+            wave_sync();
+            // (one, rest), place_sequence.rs:369-395, with |R_c| = |U| - |only_c| and |R_c \ K_c| = |U| - |K_c|
+            uint32_t n_pass = 0, n_best = 0, best_row = 0;
+            int32_t best_one = 0, best_rest = 0, best_diff = 0;
+            for (uint32_t base = 0; base < m; base += 64) {
+                const uint32_t ci = base + lane;
+                bool pass = false;
+                int32_t one = 0, rest = 0;
+                if (ci < m) {
+                    const uint32_t cn = cx.ccnt[ci], on = cx.conly[ci];
+                    if (cn) { one = (int32_t)(rm ? on : cn); rest = (int32_t)(rm ? U - cn : U - on); pass = one > rest; }
+                }
+                uint64_t pm = __ballot(pass);
+                while (pm) {  // at most one child can pass; kept general for fidelity with :519-599
+                    const int src = __ffsll((unsigned long long)pm) - 1;
+                    const int32_t o1 = __shfl(one, src), r1 = __shfl(rest, src);
+                    const int32_t diff = o1 - r1;
+                    if (n_pass == 0 || diff > best_diff) { best_diff = diff; n_best = 1; best_row = fc + base + src; best_one = o1; best_rest = r1; }
+                    else if (diff == best_diff) ++n_best;
+                    ++n_pass;
+                    pm &= pm - 1;
+                }
+            }
+            wave_sync();
+            const uint64_t pid = ((uint64_t)P.s[5] << 32) | P.s[4];
+            if (n_pass == 0) {
+                if (iteration == 1) write_record(out, r, CLS_UNCLASSIFIABLE_LEVEL1, 0, 0, 1, 0);
+                else write_record(out, r, CLS_MAX_RESOLUTION, 0, 0, (uint32_t)iteration, pid);
+                return;
+            }
+            if (n_pass > 1 && n_best != 1) { write_record(out, r, CLS_INCONCLUSIVE, (int32_t)n_pass, 0, (uint32_t)iteration, pid); return; }
+            P = load_node(nodes, best_row);
+            if (P.s[3] == 0) {
+                write_record(out, r, CLS_IDENTITY_FOUND, best_one, best_rest, (uint32_t)iteration, ((uint64_t)P.s[5] << 32) | P.s[4]);
+                return;
+            }
+            // enter the chosen child [c0, c_end): step past the occupied children before it, keep the part inside it
+            const uint32_t c0 = P.s[0], c_end = c0 + P.s[1];
+            auto enter = [&](uint32_t& v, uint32_t& vh, uint32_t& xx) {
+                bool dead = v > vh;
+                while (!dead && v < c0) {
+                    if (vh < c0) { dead = true; break; }
+                    const uint2 t = ldx<uint2, ADDR32>(half, 2 * xx + 1);
+                    v = t.x; xx = t.y;
+                }
+                if (!dead && v < c_end && v != c0) {  // a tip strictly below the chosen clade
+                    if (vh >= c_end) { const uint2 t = ldx<uint2, ADDR32>(half, 2 * xx); vh = t.x; xx = t.y; }
+                } else { v = 0xFFFFFFFFu; vh = 0; }
+            };
+            enter(vlo, vhi, x);
+#pragma unroll 1
+            for (uint32_t c = 1; c < n_chunks; ++c) {
+                uint4 g = cx.stage[c * 64 + lane];
+                enter(g.x, g.y, g.z);
+                cx.stage[c * 64 + lane] = g;
+            }
+            continue;
+        }
         const uint32_t a0 = P.s[0] + 1, a1 = P.s[6];  // first child = [a0, a1), second = [a1, end of the parent)
         // both children's records, requested ahead of the counting
         const snode_t CA = load_node(db.nodes, fc), CB = load_node(db.nodes, fc + 1);
@@ -1212,7 +1307,7 @@ __device__ __forceinline__ void place_read_fast(const DbDev& db, const PlacePara
     }
 }
 
-template <int SLOTS, int SET_BITS, bool STATS, bool ADDR32, bool CANON>
+template <int SLOTS, int SET_BITS, bool STATS, bool ADDR32, bool CANON, bool POLY>
 __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, FAST_MIN_WAVES) void place_fast_kernel(
     DbDev db, PlaceParams prm, const uint8_t* __restrict__ bases, const uint64_t* __restrict__ offsets,
     const uint32_t* __restrict__ list, const uint32_t* __restrict__ list_len, uint32_t list_n, uint32_t xcd_chunks,
@@ -1221,7 +1316,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, FAST_MIN_WAVES) void place_fa
     const uint32_t wave = threadIdx.x >> 6;
     const uint32_t packed_words = ((ascii_cap >> 4) + 2 + 3) & ~3u;  // whole 16-byte units: what follows stays 16-byte aligned
     static_assert((12u << SET_BITS) >= 16u * 64 * SLOTS, "the staging area must fit over the three tables");
-    const uint32_t per_wave = ascii_cap + 4u * packed_words + (12u << SET_BITS);
+    const uint32_t per_wave = ascii_cap + 4u * packed_words + (12u << SET_BITS) + (POLY ? 12u * FAST_MAX_ARITY + 16u : 0u);
     FastCtx cx;
     cx.ascii = smem + wave * per_wave;
     cx.packed = reinterpret_cast<uint32_t*>(cx.ascii + ascii_cap);
@@ -1229,6 +1324,9 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, FAST_MIN_WAVES) void place_fa
     cx.gkey = cx.set + (1u << SET_BITS);
     cx.gcnt = cx.gkey + (1u << SET_BITS);
     cx.stage = reinterpret_cast<uint4*>(cx.set);
+    cx.ccnt = cx.gcnt + (1u << SET_BITS);
+    cx.conly = cx.ccnt + FAST_MAX_ARITY;
+    cx.cpre = cx.conly + FAST_MAX_ARITY;
     if (xcd_chunks) {
         // locality-ordered list: XCD x (workgroups with blockIdx % 8 == x share an L2) walks the x-th
         // eighth of the list front to back, so that reads processed together share cache lines
@@ -1243,7 +1341,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, FAST_MIN_WAVES) void place_fa
             const uint64_t b0 = offsets[r], b1 = offsets[r + 1];
             const uint64_t L64 = b1 - b0;
             if (L64 >= db.k && 2 * (L64 - db.k + 1) > cap) continue;  // another class' read (classify_kernel binned it)
-            place_read_fast<SLOTS, SET_BITS, STATS, ADDR32, CANON>(db, prm, cx, bases, b0, b1, r, out, stats, profile_stop);
+            place_read_fast<SLOTS, SET_BITS, STATS, ADDR32, CANON, POLY>(db, prm, cx, bases, b0, b1, r, out, stats, profile_stop);
             wave_sync();
         }
         return;
@@ -1254,7 +1352,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, FAST_MIN_WAVES) void place_fa
     for (uint32_t i = gw; i < n_list; i += n_waves) {
         const uint32_t r = list[i];
         const uint64_t b0 = offsets[r], b1 = offsets[r + 1];
-        place_read_fast<SLOTS, SET_BITS, STATS, ADDR32, CANON>(db, prm, cx, bases, b0, b1, r, out, stats, profile_stop);
+        place_read_fast<SLOTS, SET_BITS, STATS, ADDR32, CANON, POLY>(db, prm, cx, bases, b0, b1, r, out, stats, profile_stop);
         wave_sync();
     }
 }
@@ -1709,13 +1807,14 @@ constexpr int ORDER_KEY_BITS = 32 + DIRECT_TIP_BITS;  // {first tip, record offs
 constexpr int CLS_SLOTS[N_CLASSES] = {5, 16};      // k-mers per read: 320 / 1024
 constexpr int CLS_SET_BITS[N_CLASSES] = {9, 11};   // LDS distinct-hit set: 512 / 2048 entries
 
+bool use_fast(const DbDev& db);
 bool use_order(const DbDev& db, uint32_t n_reads) {
     static const bool off = getenv("CLS_NO_ORDER") != nullptr;  // A/B experiments
-    return db.format == FMT_SPLIT && db.binary_tree && db.direct != nullptr && getenv("CLS_NO_FAST") == nullptr && !off && n_reads >= 4096;
+    return use_fast(db) && !off && n_reads >= 4096;
 }
 bool use_fast(const DbDev& db) {
     static const bool off = getenv("CLS_NO_FAST") != nullptr;  // A/B experiments
-    return db.format == FMT_SPLIT && db.binary_tree && db.direct != nullptr && !off;
+    return db.format == FMT_SPLIT && (db.binary_tree || db.max_nonleaf_arity <= FAST_MAX_ARITY) && db.direct != nullptr && !off;
 }
 uint32_t seq_cap_of(const DbDev& db, int c) { return (2 * (64 * CLS_SLOTS[c] / 2 + db.k) + 15) & ~15u; }
 // fast path: L <= 32*SLOTS + k - 1 ascii bytes (+ padding so that the 16-byte packer can over-read)
@@ -1726,7 +1825,7 @@ bool child_in_lds(const DbDev& db) { return child_ws_stride(db) != 0 && child_ws
 size_t smem_of(const DbDev& db, int c) {
     if (use_fast(db)) {
         const uint32_t ac = ascii_cap_of(db, c);
-        return (size_t)WAVES_PER_BLOCK * (ac + 4u * (((ac >> 4) + 2 + 3) & ~3u) + (12u << CLS_SET_BITS[c]));
+        return (size_t)WAVES_PER_BLOCK * (ac + 4u * (((ac >> 4) + 2 + 3) & ~3u) + (12u << CLS_SET_BITS[c]) + (db.binary_tree ? 0u : 12u * FAST_MAX_ARITY + 16u));
     }
     return (size_t)WAVES_PER_BLOCK * (seq_cap_of(db, c) + (4u << CLS_SET_BITS[c]) + 4u * 64 * CLS_SLOTS[c]) +
            (child_in_lds(db) ? (size_t)WAVES_PER_BLOCK * 2 * child_ws_stride(db) * 4 : 0);
@@ -1735,9 +1834,11 @@ size_t smem_of(const DbDev& db, int c) {
 template <int SLOTS, int SET_BITS>
 const void* kernel_of_t(const DbDev& db, bool stats) {
     if (use_fast(db)) {
-#define CLS_FAST_OF(A32, CN) (stats ? (const void*)place_fast_kernel<SLOTS, SET_BITS, true, A32, CN> : (const void*)place_fast_kernel<SLOTS, SET_BITS, false, A32, CN>)
-        if (db.addr32) return db.canonical ? CLS_FAST_OF(true, true) : CLS_FAST_OF(true, false);
-        return db.canonical ? CLS_FAST_OF(false, true) : CLS_FAST_OF(false, false);
+#define CLS_FAST_OF(A32, CN, PO) (stats ? (const void*)place_fast_kernel<SLOTS, SET_BITS, true, A32, CN, PO> : (const void*)place_fast_kernel<SLOTS, SET_BITS, false, A32, CN, PO>)
+#define CLS_FAST_OF2(A32, CN) (db.binary_tree ? CLS_FAST_OF(A32, CN, false) : CLS_FAST_OF(A32, CN, true))
+        if (db.addr32) return db.canonical ? CLS_FAST_OF2(true, true) : CLS_FAST_OF2(true, false);
+        return db.canonical ? CLS_FAST_OF2(false, true) : CLS_FAST_OF2(false, false);
+#undef CLS_FAST_OF2
 #undef CLS_FAST_OF
     }
     if (db.format == FMT_SPLIT) {
@@ -1885,13 +1986,15 @@ hipError_t launch_place(const DbDev& db, const PlaceParams& prm, const PlacePlan
             const uint32_t ac = ascii_cap_of(db, c);
             const uint32_t* lst = c == 0 ? list0 : lists[c];
             const uint32_t ln = c == 0 ? list0_n : 0u, xc = c == 0 ? xcd_chunks : 0u;
-#define CLS_LAUNCH_FAST(ST, A32, CN)                                                                                              \
-    hipLaunchKernelGGL((place_fast_kernel<SLOTS, SET_BITS, ST, A32, CN>), grid, block, smem, stream, db, prm, d_bases, d_offsets, \
+#define CLS_LAUNCH_FAST(ST, A32, CN, PO)                                                                                              \
+    hipLaunchKernelGGL((place_fast_kernel<SLOTS, SET_BITS, ST, A32, CN, PO>), grid, block, smem, stream, db, prm, d_bases, d_offsets, \
                        lst, counts + c, ln, xc, d_out, d_stats, ac, profile_stop)
-#define CLS_LAUNCH_FAST2(ST, A32) do { if (db.canonical) CLS_LAUNCH_FAST(ST, A32, true); else CLS_LAUNCH_FAST(ST, A32, false); } while (0)
+#define CLS_LAUNCH_FAST3(ST, A32, CN) do { if (db.binary_tree) CLS_LAUNCH_FAST(ST, A32, CN, false); else CLS_LAUNCH_FAST(ST, A32, CN, true); } while (0)
+#define CLS_LAUNCH_FAST2(ST, A32) do { if (db.canonical) CLS_LAUNCH_FAST3(ST, A32, true); else CLS_LAUNCH_FAST3(ST, A32, false); } while (0)
             if (db.addr32) { if (st) CLS_LAUNCH_FAST2(true, true); else CLS_LAUNCH_FAST2(false, true); }
             else { if (st) CLS_LAUNCH_FAST2(true, false); else CLS_LAUNCH_FAST2(false, false); }
 #undef CLS_LAUNCH_FAST2
+#undef CLS_LAUNCH_FAST3
 #undef CLS_LAUNCH_FAST
             return;
         }

@@ -3,6 +3,11 @@ import sys
 
 import pytest
 
+try:  # PyTorch ships its own ROCm runtime: load it before libclsplace.so pulls in the system's, whatever test runs first
+    import torch  # noqa: F401
+except Exception:  # pragma: no cover
+    pass
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

@@ -65,7 +65,7 @@ def test_sets_with_nothing_below_the_root(k, collapse):
     for kw in (dict(), dict(min_match_coverage=1.0), dict(remove_intersection=True)):
         _check(flat, bases, offsets, kw)
     with engine.PlacementDb(flat, device=0) as db:
-        assert db.info.format == 1 and db.info.direct_table == (1 if k <= 15 and collapse == 0.0 else 0)
+        assert db.info.format == 1 and db.info.direct_table == (1 if k <= 15 else 0)
 
 
 def test_ragged_and_edge_reads():
@@ -226,7 +226,8 @@ def test_index_format_selection():
         (SynthDb(60, 300, 8, 4), None, (1, 1, 2)),                      # closed sets, binary tree, k <= 15, both strands indexed: fast path, one lookup per window
         (SynthDb(60, 300, 8, 4), -1.0, (1, 1, 1)),                      # the same, not strand-symmetric: fast path, both strands looked up
         (SynthDb(60, 300, 17, 4), None, (1, 1, 0)),                     # k > 15: split records, murmur probe path
-        (SynthDb(60, 300, 8, 4, collapse_prob=0.4), None, (1, 0, 0)),   # polytomies: split records, child walk
+        (SynthDb(60, 300, 8, 4, collapse_prob=0.4), None, (1, 0, 2)),   # polytomies: fast path with the per-group child walk
+        (SynthDb(60, 300, 17, 4, collapse_prob=0.4), None, (1, 0, 0)),  # polytomies, k > 15: split records, wave-wide child walk
         (SynthDb(60, 300, 8, 4), 0.2, (0, 1, 0)),                       # a node set that is not closed: sorted lists
     ]
     for s, drop, want in cases:

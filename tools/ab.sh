@@ -1,3 +1,2 @@
-B() { env $1 timeout -k 10 200 python bench.py --steps 10 --warmup 2 --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$1', d['value'], d['ms_per_step'], d['roofline']['kernel_ms'])"; }
-B A=1
-B A=2
+timeout -k 10 1000 python -m pytest tests/test_gpu_parity.py -x -q -m gpu 2>&1 | tail -3
+timeout -k 10 300 python tools/poly_probe.py 12 2>&1 | tail -2
