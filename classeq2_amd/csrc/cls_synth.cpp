@@ -119,7 +119,7 @@ extern "C" int cls_synth_db_create(const cls_synth_cfg* cfg, cls_synth_db** out)
                 while ((1u << need) < n) ++need;  // ceil(log2 n)
                 if (cfg->max_depth && (uint32_t)d + need + 2 >= cfg->max_depth) {
                     a = n / 2;  // finish balanced inside the depth cap
-                } else if (cfg->deep && rng.unit() < 0.9) {
+                } else if (cfg->deep && (cfg->deep >= 2 || rng.unit() < 0.9)) {  // deep = 2: a pure ladder (depth ~ n/2), for tests
                     uint32_t small = 1 + (uint32_t)rng.below(3);
                     if (small > n - 1) small = n - 1;
                     a = rng.below(2) ? small : n - small;

@@ -133,6 +133,21 @@ def test_long_reads_workspace_kernel(k, collapse, drop, deep):
     assert (got["status"] != _abi.ERR_READ_TOO_LONG).all()
 
 
+@pytest.mark.parametrize("k,collapse", [(9, 0.0), (9, 0.3), (17, 0.0)])
+def test_ladder_tree_deeper_than_the_iteration_cap(k, collapse):
+    """A ladder-like tree of depth > 1000 (BASELINE config 5 is capped at 900 for this reason): with the default
+    cap the deepest reads end in ERR_MAX_ITER at level 1001 (place_sequence.rs:295-301), with a larger one they
+    resolve more than a thousand levels down."""
+    s = SynthDb(2300, 60, k, 4, deep=2, edge_sub_rate=0.02, collapse_prob=collapse)
+    assert s.max_depth > (1050 if collapse == 0.0 else 600)
+    bases, offsets, _ = s.reads(300, 60, err=0.0, frac_random=0.02)
+    got = _check(s.flat, bases, offsets, {}, threads=8)
+    got5k = _check(s.flat, bases, offsets, dict(max_iterations=5000, remove_intersection=True), threads=8)
+    if collapse == 0.0:
+        assert (got["status"] == _abi.ERR_MAX_ITER).sum() > 10 and (got["levels"][got["status"] == _abi.ERR_MAX_ITER] == 1001).all()
+        assert got5k["levels"].max() > 1050 and (got5k["status"] != _abi.ERR_MAX_ITER).all()
+
+
 def test_long_and_short_reads_in_one_batch():
     """One batch through all four kernels (320 / 1024 / 8192 k-mers and the workspace kernel), an invalid base
     in a long read, and a long read of random bases."""
