@@ -1543,7 +1543,25 @@ __global__ __launch_bounds__(LONG_THREADS) void place_long_kernel(DbDev db, Plac
             return rc ? (uint8_t)(c ^ ((c & 2) ? 0x04 : 0x15)) : c;  // A<->T, C<->G
         };
         // ---- A2. hash, probe, minimizer-bucket filter, distinct hashes ---------------------------------
+        const bool use_direct = SPLIT && db.direct != nullptr;  // k <= 15, every entry in the bucket of its own prefix: no hash, no filter
         for (uint32_t j = tid; j < nk; j += NT) {
+            if (use_direct) {
+                uint32_t code = 0;
+                for (uint32_t t = 0; t < k; ++t) code |= (uint32_t)((kmer_char(j, t) >> 1) & 3u) << (2 * t);  // A0 C1 T2 G3, first base in the low bits
+                const uint32_t off = db.direct[4 * (size_t)code];  // header record of the k-mer, 0 = not in the index
+                uint32_t e = SET_EMPTY;
+                if (off) {
+                    uint32_t pos = (off * 2654435761u) & (set_size - 1);
+                    for (;;) {
+                        const uint32_t old = atomicCAS(&set[pos], SET_EMPTY, off);
+                        if (old == SET_EMPTY) { e = off; break; }
+                        if (old == off) break;
+                        pos = (pos + 1) & (set_size - 1);
+                    }
+                }
+                ent[j] = e;
+                continue;
+            }
             const uint64_t h = murmur3_h1([&](uint32_t t) { return kmer_char(j, t); }, k);
             const uint64_t mz = murmur3_h1([&](uint32_t t) { return kmer_char(j, t); }, m_eff);
             bool hit = false;
@@ -1655,35 +1673,59 @@ __global__ __launch_bounds__(LONG_THREADS) void place_long_kernel(DbDev db, Plac
             __syncthreads();
             const uint32_t last_end = m ? nodes[fc + m - 1].pre + nodes[fc + m - 1].size : 0u;
             uint32_t U = 0;
-            for (uint32_t j = tid; j < n_act; j += NT) {
+            // One atomic per wavefront and distinct child instead of one per k-mer: on a binary clade every k-mer of
+            // the read votes for one of two counters, and 20 000 atomics on two addresses per level was the kernel.
+            auto add_grouped = [&](uint32_t* arr, bool pred, uint32_t ci) {  // wave-uniform call
+                uint64_t todo = __ballot(pred);
+                while (todo) {
+                    const int leader = __ffsll((unsigned long long)todo) - 1;
+                    const uint32_t c = __shfl(ci, leader);
+                    const uint64_t same = __ballot(pred && ci == c);
+                    if ((int)lane == leader) __hip_atomic_fetch_add(&arr[c], (uint32_t)__popcll(same), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    todo &= ~same;
+                }
+            };
+            for (uint32_t base = 0; base < n_act; base += NT) {
+                const uint32_t j = base + tid;
+                const bool valid = j < n_act;
                 uint32_t nin = 0, which = 0;
                 if constexpr (SPLIT) {
-                    uint32_t v = cur[j], xx = cur[2 * (size_t)cap + j];
-                    const uint32_t vh = cur[(size_t)cap + j];
-                    while (v < last_end) {  // v lies under exactly one non-LEAF child: the last one starting at or before it
-                        uint32_t lo_ = 0, hi_ = m;
-                        while (hi_ - lo_ > 1) { const uint32_t mid = (lo_ + hi_) >> 1; if (nodes[fc + mid].pre <= v) lo_ = mid; else hi_ = mid; }
-                        const uint32_t c_end = nodes[fc + lo_].pre + nodes[fc + lo_].size;
-                        __hip_atomic_fetch_add(&cnt[lo_], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        if (nin == 0) which = lo_;
-                        if (nin < 2) ++nin;
-                        if (vh < c_end) break;          // no tip beyond this child
-                        const uint4 t = recs[xx];       // first tip beyond it, and the split of the rest
-                        v = t.z; xx = t.w;
-                    }
-                } else {
-                    const uint32_t lo = cur[j], hi = cur[(size_t)cap + j], vlo = cur[2 * (size_t)cap + j], vhi = cur[3 * (size_t)cap + j];
-                    const bool closed = cur[4 * (size_t)cap + j] != 0;
-                    for (uint32_t ci = 0; ci < m; ++ci) {
-                        const uint32_t c0 = nodes[fc + ci].pre, c1 = c0 + nodes[fc + ci].size;
-                        if (member_of(post, lo, hi, vlo, vhi, closed, c0, c1)) {
-                            __hip_atomic_fetch_add(&cnt[ci], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            if (nin == 0) which = ci;
+                    uint32_t v = valid ? cur[j] : 0xFFFFFFFFu, xx = valid ? cur[2 * (size_t)cap + j] : 0u;
+                    const uint32_t vh = valid ? cur[(size_t)cap + j] : 0u;
+                    bool walking = valid && v < last_end;
+                    while (__ballot(walking)) {  // v lies under exactly one non-LEAF child: the last one starting at or before it
+                        uint32_t lo_ = 0, c_end = 0;
+                        if (walking) {
+                            uint32_t hi_ = m;
+                            while (hi_ - lo_ > 1) { const uint32_t mid = (lo_ + hi_) >> 1; if (nodes[fc + mid].pre <= v) lo_ = mid; else hi_ = mid; }
+                            c_end = nodes[fc + lo_].pre + nodes[fc + lo_].size;
+                        }
+                        add_grouped(cnt, walking, lo_);
+                        if (walking) {
+                            if (nin == 0) which = lo_;
                             if (nin < 2) ++nin;
+                            if (vh < c_end) walking = false;  // no tip beyond this child
+                            else {
+                                const uint4 t = recs[xx];     // first tip beyond it, and the split of the rest
+                                v = t.z; xx = t.w;
+                                walking = v < last_end;
+                            }
                         }
                     }
+                } else {
+                    const uint32_t lo = valid ? cur[j] : 0u, hi = valid ? cur[(size_t)cap + j] : 0u;
+                    const uint32_t vlo = valid ? cur[2 * (size_t)cap + j] : 0xFFFFFFFFu, vhi = valid ? cur[3 * (size_t)cap + j] : 0u;
+                    const bool closed = valid && cur[4 * (size_t)cap + j] != 0;
+                    for (uint32_t ci = 0; ci < m; ++ci) {
+                        const uint32_t c0 = nodes[fc + ci].pre, c1 = c0 + nodes[fc + ci].size;
+                        const bool in = valid && member_of(post, lo, hi, vlo, vhi, closed, c0, c1);
+                        const uint64_t mm = __ballot(in);
+                        if (mm && lane == (uint32_t)(__ffsll((unsigned long long)mm) - 1))
+                            __hip_atomic_fetch_add(&cnt[ci], (uint32_t)__popcll(mm), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (in) { if (nin == 0) which = ci; if (nin < 2) ++nin; }
+                    }
                 }
-                if (nin == 1) __hip_atomic_fetch_add(&only[which], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                add_grouped(only, nin == 1, which);
                 U += nin ? 1u : 0u;
             }
             { uint32_t v[1] = {U}; __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent"); long_sum<1>(v, sh); U = v[0]; }
