@@ -69,10 +69,22 @@ def cpu_baseline(synth, cfg, budget_s=15.0):
     t0 = time.time()
     port.place_batch(bases, offsets, threads=cores)
     dt = time.time() - t0
+    # what the unmodified Rust path would cost: the port + the reference's per-query deep clone of the index
+    # (place_sequence.rs:77-80) and per-bucket key-set rebuild (kmers_map.rs:58-62); an estimate, on a small sample
+    port.set_reference_cost(True)
+    rc_threads = min(cores, 16)  # (3 M allocations per query: more threads only fight over the allocator)
+    m = 2 * rc_threads
+    t0 = time.time()
+    port.place_batch(bases[: m * cfg["read_len"]], offsets[: m + 1], threads=rc_threads)
+    dt_ref = time.time() - t0
     port.close()
     return {
         "value": n / dt, "unit": "placements/s", "cores": cores, "kind": "port",
         "sample": f"first {n} reads of the same stream, {dt:.1f} s wall on {cores} threads (index build {build_s:.1f} s untimed)",
+        "reference_cost_estimate": {"value": m / dt_ref, "unit": "placements/s", "cores": rc_threads,
+                                    "sample": f"first {m} reads, {dt_ref:.1f} s wall",
+                                    "what": "the port plus the reference's per-query index clone and bucket key-set rebuild "
+                                            "(place_sequence.rs:77-80, kmers_map.rs:58-62); an estimate, not the Rust binary"},
     }
 
 

@@ -97,6 +97,9 @@ struct cls_oracle {
     uint64_t* node_off;     /* per k-mer, into `nodes_sorted`                  */
     uint64_t* nodes_sorted; /* each k-mer's HashSet<u64> as a sorted array     */
     uint32_t* n_leaf_ids;   /* per k-mer: LEAF-kind ids in its set (stats)     */
+    uint64_t* bucket_off;   /* [n_buckets+1] k-mer ranges of the buckets (descriptor order) */
+    uint64_t* kmer_hash;    /* hashes in descriptor order                       */
+    int reference_cost;     /* also pay the reference's per-query overheads (cls_oracle_set_reference_cost) */
 };
 typedef struct cls_oracle cls_oracle;
 
@@ -121,7 +124,7 @@ static int set_contains(const uint64_t* s, uint64_t n, uint64_t v) {
 void cls_oracle_destroy(cls_oracle* o) {
     if (!o) return;
     free(o->nodes); free(o->bucket_key); free(o->by_hash); free(o->node_off);
-    free(o->nodes_sorted); free(o->n_leaf_ids); free(o);
+    free(o->nodes_sorted); free(o->n_leaf_ids); free(o->bucket_off); free(o->kmer_hash); free(o);
 }
 
 int cls_oracle_create(const cls_db_desc* d, cls_oracle** out) {
@@ -137,12 +140,16 @@ int cls_oracle_create(const cls_db_desc* d, cls_oracle** out) {
     o->node_off = malloc(8 * (d->n_kmers + 1));
     o->nodes_sorted = malloc(8 * (tot + 1));
     o->n_leaf_ids = calloc(d->n_kmers + 1, 4);
-    if (!o->nodes || !o->bucket_key || !o->by_hash || !o->node_off || !o->nodes_sorted || !o->n_leaf_ids) {
+    o->bucket_off = malloc(8 * (d->n_buckets + 1));
+    o->kmer_hash = malloc(8 * (d->n_kmers + 1));
+    if (!o->nodes || !o->bucket_key || !o->by_hash || !o->node_off || !o->nodes_sorted || !o->n_leaf_ids || !o->bucket_off || !o->kmer_hash) {
         cls_oracle_destroy(o);
         return CLS_E_NOMEM;
     }
     memcpy(o->nodes, d->nodes, sizeof(cls_node) * d->n_nodes);
     if (d->n_buckets) memcpy(o->bucket_key, d->bucket_key, 8 * d->n_buckets);
+    if (d->n_buckets) memcpy(o->bucket_off, d->bucket_kmer_off, 8 * (d->n_buckets + 1)); else o->bucket_off[0] = 0;
+    if (d->n_kmers) memcpy(o->kmer_hash, d->kmer_hash, 8 * d->n_kmers);
     /* sorted list of LEAF-kind clade ids, for the leaf_postings statistic */
     uint64_t* leaf_ids = malloc(8 * (size_t)d->n_nodes);
     uint64_t n_leaf = 0;
@@ -343,6 +350,71 @@ static void place_one(const cls_oracle* o, const char* seq, uint64_t L, int32_t 
     }
 }
 
+/* ---- "reference cost" mode ----------------------------------------------------------------
+ * What the reference does per QUERY on top of the algorithm (SURVEY.md 3.3 hot spots i-ii), so that a timing of
+ * this port can stand in for the unmodified Rust path (an estimate; never used for results):
+ *   (i)  place_sequence.rs:77-80  `tree.kmers_map.to_owned()`: a deep clone of the whole index -- every bucket's
+ *        HashMap<u64, HashSet<u64>> and every k-mer's HashSet<u64>, one allocation + copy each, dropped at the end;
+ *   (ii) kmers_map.rs:58-62       MinimizerValue::get_overlapping_hashed_kmers collects ALL keys of every
+ *        touched bucket into a fresh HashSet before intersecting with the query's hashes. */
+static uint64_t refcost_overhead(const cls_oracle* o, const char* seq, uint64_t L) {
+    uint64_t sink = 0;
+    void** sets = malloc(sizeof(void*) * (o->n_kmers + 1));
+    void** maps = malloc(sizeof(void*) * (o->n_buckets + 1));
+    if (!sets || !maps) { free(sets); free(maps); return 0; }
+    for (uint64_t b = 0; b < o->n_buckets; b++) {  /* (i) clone */
+        const uint64_t lo = o->bucket_off[b], hi = o->bucket_off[b + 1];
+        uint64_t* keys = malloc(16 * (hi - lo) + 16);  /* the bucket's map: key + pointer per entry */
+        maps[b] = keys;
+        for (uint64_t j = lo; j < hi; j++) {
+            const uint64_t n = o->node_off[j + 1] - o->node_off[j];
+            uint64_t* set = malloc(8 * n + 16);
+            if (set) { memcpy(set, o->nodes_sorted + o->node_off[j], 8 * n); sink += set[n ? n - 1 : 0]; }
+            sets[j] = set;
+            if (keys) { keys[2 * (j - lo)] = o->kmer_hash[j]; keys[2 * (j - lo) + 1] = (uint64_t)(uintptr_t)set; }
+        }
+    }
+    if (L >= o->k) {  /* (ii) key set of every bucket a query minimizer names */
+        const uint64_t nf = L - o->k + 1;
+        unsigned char* touched = calloc(o->n_buckets + 1, 1);
+        char up[64];
+        const uint64_t mm = o->m < o->k ? o->m : o->k;
+        for (int strand = 0; strand < 2 && touched && mm <= sizeof up; strand++)
+            for (uint64_t p = 0; p < nf; p++) {
+                for (uint64_t t = 0; t < mm; t++) {
+                    char c = strand == 0 ? seq[p + t] : seq[L - 1 - p - t];
+                    if (c >= 'a' && c <= 'z') c -= 32;
+                    if (strand) c = c == 'A' ? 'T' : c == 'T' ? 'A' : c == 'C' ? 'G' : c == 'G' ? 'C' : c;
+                    up[t] = c;
+                }
+                const uint64_t mz = mm ? cls_oracle_murmur3_h1(up, mm) : 0;
+                for (uint64_t b = 0; b < o->n_buckets; b++) if (o->bucket_key[b] == mz) touched[b] = 1;
+            }
+        for (uint64_t b = 0; touched && b < o->n_buckets; b++) {
+            if (!touched[b]) continue;
+            const uint64_t lo = o->bucket_off[b], hi = o->bucket_off[b + 1];
+            uint64_t cap = 8;
+            while (cap < 2 * (hi - lo)) cap <<= 1;
+            uint64_t* tab = calloc(cap, 8);
+            if (!tab) continue;
+            for (uint64_t j = lo; j < hi; j++) {  /* HashSet<u64>::insert of every key */
+                uint64_t h = o->kmer_hash[j] | 1, i = (h * 0x9E3779B97F4A7C15ull) & (cap - 1);
+                while (tab[i] && tab[i] != h) i = (i + 1) & (cap - 1);
+                tab[i] = h;
+            }
+            sink += tab[cap / 2];
+            free(tab);
+        }
+        free(touched);
+    }
+    for (uint64_t j = 0; j < o->n_kmers; j++) free(sets[j]);
+    for (uint64_t b = 0; b < o->n_buckets; b++) free(maps[b]);
+    free(sets); free(maps);
+    return sink;
+}
+
+void cls_oracle_set_reference_cost(cls_oracle* o, int on) { if (o) o->reference_cost = on != 0; }
+
 typedef struct {
     const cls_oracle* o; const char* bases; const uint64_t* off; uint32_t lo, hi;
     int32_t max_iter; double cov; int rm; cls_placement* out; cls_query_stats* st;
@@ -351,8 +423,12 @@ typedef struct {
 static void* worker(void* arg) {
     job* j = arg;
     scratch S; memset(&S, 0, sizeof S);
-    for (uint32_t i = j->lo; i < j->hi; i++)
+    volatile uint64_t sink = 0;
+    for (uint32_t i = j->lo; i < j->hi; i++) {
+        if (j->o->reference_cost) sink += refcost_overhead(j->o, j->bases + j->off[i], j->off[i + 1] - j->off[i]);
         place_one(j->o, j->bases + j->off[i], j->off[i + 1] - j->off[i], j->max_iter, j->cov, j->rm, &S, &j->out[i], j->st ? &j->st[i] : NULL);
+    }
+    (void)sink;
     free(S.hashes.p); free(S.mins.p); free(S.ent_kmer.p); free(S.ent_hidx.p); free(S.sets.p); free(S.child_rows.p); free(S.cand_rows.p); free(S.buf.p);
     return NULL;
 }

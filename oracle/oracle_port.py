@@ -42,6 +42,8 @@ def lib():
         L.cls_oracle_create.restype = C.c_int
         L.cls_oracle_destroy.argtypes = [C.c_void_p]
         L.cls_oracle_destroy.restype = None
+        L.cls_oracle_set_reference_cost.argtypes = [C.c_void_p, C.c_int]
+        L.cls_oracle_set_reference_cost.restype = None
         L.cls_oracle_place_batch.argtypes = [
             C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(_abi.Params), C.c_int, C.c_void_p, C.c_void_p,
         ]
@@ -86,6 +88,10 @@ class OraclePort:
             self.close()
         except Exception:
             pass
+
+    def set_reference_cost(self, on: bool) -> None:
+        """Also pay the reference's per-query index clone + bucket key-set rebuild (timing estimates only)."""
+        lib().cls_oracle_set_reference_cost(self._h, 1 if on else 0)
 
     def place_batch(self, bases: np.ndarray, offsets: np.ndarray, params=None, threads: int = 1, want_stats=False):
         bases = np.ascontiguousarray(bases, dtype=np.uint8)
