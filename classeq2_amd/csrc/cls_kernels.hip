@@ -33,6 +33,9 @@ constexpr int WAVES_PER_BLOCK = 4;
 #ifndef FAST_MIN_WAVES
 #define FAST_MIN_WAVES 5  // 96 VGPRs: 5 workgroups per CU measured best on C3 (4: 9.2 ms, 5: 8.5, 6: 9.1 with more spills)
 #endif
+#ifndef FAST_MIN_WAVES_WIDE
+#define FAST_MIN_WAVES_WIDE 4  // the 16-slot class keeps more state per lane: forcing 96 VGPRs on it spills 74 of them
+#endif
 constexpr uint32_t SET_EMPTY = 0xFFFFFFFFu;
 
 __device__ __forceinline__ void wave_sync() {
@@ -948,6 +951,7 @@ struct FastCtx {
     uint32_t* conly;   // ... and those under no other one
     uint32_t* cpre;    // ... and where each child's pre-order interval starts (+ the end of the last one)
 };
+constexpr int FAST_SLOTS_NARROW = 5;       // slots of the narrow wave-per-read class (CLS_SLOTS[0]); the wide one skips its reads
 constexpr uint32_t FAST_MAX_ARITY = 256;  // non-LEAF children per clade the fast path keeps counters for
 
 // Front of the fast path, shared with order_key_kernel: the read -> LDS (upper-cased, validated),
@@ -959,7 +963,7 @@ constexpr uint32_t FAST_MAX_ARITY = 256;  // non-LEAF children per clade the fas
 template <int SLOTS, int SET_BITS, bool ADDR32>
 __device__ __forceinline__ bool fast_front(const DbDev& db, const FastCtx& cx, const uint8_t* __restrict__ bases, uint64_t b0,
                                            uint32_t L, uint32_t nf, uint32_t nk, uint4 (&ent)[SLOTS], uint32_t (&kw)[SLOTS],
-                                           uint32_t sample_shift = 32, bool canonical = false) {
+                                           uint32_t sample_shift = 32, bool canonical = false, uint32_t table_bits = SET_BITS) {
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t k = db.k;
     bool bad = false;
@@ -971,7 +975,7 @@ __device__ __forceinline__ bool fast_front(const DbDev& db, const FastCtx& cx, c
         cx.ascii[i] = c;
     }
 #pragma unroll 1
-    for (uint32_t i = lane; i < (1u << SET_BITS); i += 64) {
+    for (uint32_t i = lane; i < (1u << table_bits); i += 64) {  // (only the part of the tables this read will use)
         cx.set[i] = SET_EMPTY;
         if (SET_BITS) { cx.gkey[i] = SET_EMPTY; cx.gcnt[i] = 0; }
     }
@@ -1045,7 +1049,15 @@ __device__ __forceinline__ void place_read_fast(const DbDev& db, const PlacePara
     constexpr int LS = CANON ? (SLOTS + 1) / 2 : SLOTS;
     uint4 ent[LS];
     uint32_t kw[LS];
-    if (!fast_front<LS, SET_BITS, ADDR32>(db, cx, bases, b0, L, nf, CANON ? nf : nk, ent, kw, 32, CANON)) {
+    // the wide class sizes its LDS tables by the read (clearing 3 x 2048 entries cost more than placing a 250 bp read)
+    uint32_t tb = SET_BITS;
+    if constexpr (SET_BITS > 9) {
+        const uint32_t want = 2 * (CANON ? nf : nk);
+        tb = 9;
+        while ((1u << tb) < want && tb < (uint32_t)SET_BITS) ++tb;
+        tb = uniform(tb);
+    }
+    if (!fast_front<LS, SET_BITS, ADDR32>(db, cx, bases, b0, L, nf, CANON ? nf : nk, ent, kw, 32, CANON, tb)) {
         put_stats(0, 0, 0, 0);
         write_record(out, r, CLS_ERR_INVALID_BASE, 0, 0, 0, 0);
         return;
@@ -1056,13 +1068,13 @@ __device__ __forceinline__ void place_read_fast(const DbDev& db, const PlacePara
     for (int s = 0; s < LS; ++s) {
         if (ent[s].x != 0) {
             const uint32_t key = ent[s].x;
-            uint32_t pos = (key * 2654435761u) >> (32 - SET_BITS);
+            uint32_t pos = (key * 2654435761u) >> (32 - tb);
 #pragma unroll 1
             for (;;) {
                 const uint32_t old = atomicCAS(&cx.set[pos], SET_EMPTY, key);
                 if (old == SET_EMPTY) break;
                 if (old == key) { ent[s] = uint4{0u, 0u, 0xFFFFFFFFu, 0u}; kw[s] = 0; break; }
-                pos = (pos + 1) & ((1u << SET_BITS) - 1);
+                pos = (pos + 1) & ((1u << tb) - 1);
             }
         }
     }
@@ -1108,13 +1120,13 @@ __device__ __forceinline__ void place_read_fast(const DbDev& db, const PlacePara
             pos[s] = 0;
             if (lo_ <= hi_) {  // has tips below the root (absent / tip-less entries hold {MAX, 0})
                 const uint32_t key = ent[s].y ? ent[s].y : (0x80000000u | lo_);
-                uint32_t p = (key * 2654435761u) >> (32 - SET_BITS);
+                uint32_t p = (key * 2654435761u) >> (32 - tb);
 #pragma unroll 1
                 for (;;) {
                     const uint32_t old = atomicCAS(&cx.gkey[p], SET_EMPTY, key);
                     if (old == SET_EMPTY) { owner |= 1u << s; break; }
                     if (old == key) break;
-                    p = (p + 1) & ((1u << SET_BITS) - 1);
+                    p = (p + 1) & ((1u << tb) - 1);
                 }
                 atomicAdd(&cx.gcnt[p], kw[s]);
                 pos[s] = p;
@@ -1308,7 +1320,7 @@ __device__ __forceinline__ void place_read_fast(const DbDev& db, const PlacePara
 }
 
 template <int SLOTS, int SET_BITS, bool STATS, bool ADDR32, bool CANON, bool POLY>
-__global__ __launch_bounds__(64 * WAVES_PER_BLOCK, FAST_MIN_WAVES) void place_fast_kernel(
+__global__ __launch_bounds__(64 * WAVES_PER_BLOCK, SLOTS <= 5 ? FAST_MIN_WAVES : FAST_MIN_WAVES_WIDE) void place_fast_kernel(
     DbDev db, PlaceParams prm, const uint8_t* __restrict__ bases, const uint64_t* __restrict__ offsets,
     const uint32_t* __restrict__ list, const uint32_t* __restrict__ list_len, uint32_t list_n, uint32_t xcd_chunks,
     cls_placement* __restrict__ out, cls_query_stats* __restrict__ stats, uint32_t ascii_cap, uint32_t profile_stop) {
@@ -1330,6 +1342,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, FAST_MIN_WAVES) void place_fa
     if (xcd_chunks) {
         // locality-ordered list: XCD x (workgroups with blockIdx % 8 == x share an L2) walks the x-th
         // eighth of the list front to back, so that reads processed together share cache lines
+        if (SLOTS > FAST_SLOTS_NARROW && *list_len == 0) return;  // no read of the wide class in the batch (the list holds every class)
         const uint32_t n_list = list_n;
         const uint32_t xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3, bpx = gridDim.x >> 3;
         const uint32_t chunk = (n_list + 7u) >> 3;
@@ -1341,6 +1354,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, FAST_MIN_WAVES) void place_fa
             const uint64_t b0 = offsets[r], b1 = offsets[r + 1];
             const uint64_t L64 = b1 - b0;
             if (L64 >= db.k && 2 * (L64 - db.k + 1) > cap) continue;  // another class' read (classify_kernel binned it)
+            if (SLOTS > FAST_SLOTS_NARROW && (L64 < db.k || 2 * (L64 - db.k + 1) <= 64 * FAST_SLOTS_NARROW)) continue;
             place_read_fast<SLOTS, SET_BITS, STATS, ADDR32, CANON, POLY>(db, prm, cx, bases, b0, b1, r, out, stats, profile_stop);
             wave_sync();
         }
@@ -1366,7 +1380,8 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void order_key_kernel(DbDev d
                                                                        const uint64_t* __restrict__ offsets, uint32_t n_reads,
                                                                        uint64_t* __restrict__ keys, uint32_t* __restrict__ idx,
                                                                        uint32_t ascii_cap, uint32_t tip_bits, uint32_t spec_lg,
-                                                                       uint32_t block_shift, uint32_t sample_shift, uint32_t fwd_only) {
+                                                                       uint32_t block_shift, uint32_t sample_shift, uint32_t fwd_only,
+                                                                       uint32_t key_cap) {
     extern __shared__ __align__(16) uint8_t smem[];
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const uint32_t packed_words = ((ascii_cap >> 4) + 2 + 3) & ~3u;  // whole 16-byte units: what follows stays 16-byte aligned
@@ -1382,8 +1397,10 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void order_key_kernel(DbDev d
     for (uint32_t r = gw; r < n_reads; r += n_waves) {
         const uint64_t b0 = offsets[r], L64 = offsets[r + 1] - b0;
         uint64_t key = ~0ull;
-        if (L64 >= db.k && 2 * (L64 - db.k + 1) <= (uint64_t)(64 * SLOTS)) {
-            const uint32_t L = (uint32_t)L64, nf = L - db.k + 1, nk = 2 * nf;
+        if (L64 >= db.k && 2 * (L64 - db.k + 1) <= (uint64_t)key_cap) {
+            // reads of the next class (up to key_cap k-mers) are keyed by their first 32*SLOTS windows: the same
+            // sorted list then orders both wave-per-read kernels
+            const uint32_t L = (uint32_t)std::min<uint64_t>(L64, 32 * SLOTS + db.k - 1), nf = L - db.k + 1, nk = 2 * nf;
             uint4 ent[SLOTS];
             uint32_t kw[SLOTS];
             // one lookup per window, of the smaller of the k-mer and its reverse complement: an index built from
@@ -1939,6 +1956,7 @@ PlacePlan plan_place(const DbDev& db, uint32_t n_reads, uint32_t n_cu, bool stat
         // on tip-set groups, a read's footprint in the XCD's 4 MiB L2 is small enough that more reads in flight
         // keep paying (C3: 2 per CU 15.5 ms, 3: 11.2, 4: 9.3; a grid beyond residency only adds a tail)
         p.grid[0] = std::max<uint32_t>(8, p.grid[0] & ~7u);  // whole octets of workgroups: one slice of the list per XCD
+        p.grid[1] = std::max<uint32_t>(8, p.grid[1] & ~7u);
         {   // the key kernel is bound by the latency of random table reads: every wave the CU can hold
             static const int forced_key = [] { const char* e = getenv("CLS_KEY_BLOCKS_PER_CU"); return e ? atoi(e) : 0; }();
             int per_cu = forced_key;
@@ -2009,10 +2027,10 @@ hipError_t launch_place(const DbDev& db, const PlaceParams& prm, const PlacePlan
         const size_t smem_k = (size_t)WAVES_PER_BLOCK * (ac + 4u * (((ac >> 4) + 2 + 3) & ~3u) + 16u);
         if (db.addr32)
             hipLaunchKernelGGL((order_key_kernel<CLS_SLOTS[0], true>), dim3(plan.grid_key), dim3(64 * WAVES_PER_BLOCK), smem_k, stream, db,
-                               d_bases, d_offsets, n_reads, keys_in, idx_in, ac, tip_bits, spec_lg, block_shift, sample_shift, fwd_only);
+                               d_bases, d_offsets, n_reads, keys_in, idx_in, ac, tip_bits, spec_lg, block_shift, sample_shift, fwd_only, (uint32_t)(64 * CLS_SLOTS[1]));
         else
             hipLaunchKernelGGL((order_key_kernel<CLS_SLOTS[0], false>), dim3(plan.grid_key), dim3(64 * WAVES_PER_BLOCK), smem_k, stream, db,
-                               d_bases, d_offsets, n_reads, keys_in, idx_in, ac, tip_bits, spec_lg, block_shift, sample_shift, fwd_only);
+                               d_bases, d_offsets, n_reads, keys_in, idx_in, ac, tip_bits, spec_lg, block_shift, sample_shift, fwd_only, (uint32_t)(64 * CLS_SLOTS[1]));
         e = sort_pairs(d_ws + plan.sort_off_words, plan.sort_bytes, keys_in, keys_out, idx_in, idx_out, n_reads, ORDER_KEY_BITS, stream);
         if (e != hipSuccess) return e;
         list0 = idx_out;
@@ -2026,8 +2044,8 @@ hipError_t launch_place(const DbDev& db, const PlaceParams& prm, const PlacePlan
         const size_t smem = smem_of(db, c);
         if (use_fast(db)) {
             const uint32_t ac = ascii_cap_of(db, c);
-            const uint32_t* lst = c == 0 ? list0 : lists[c];
-            const uint32_t ln = c == 0 ? list0_n : 0u, xc = c == 0 ? xcd_chunks : 0u;
+            const uint32_t* lst = xcd_chunks ? list0 : lists[c];  // ordered: one list for both classes, each skips the other's reads
+            const uint32_t ln = list0_n, xc = xcd_chunks;
 #define CLS_LAUNCH_FAST(ST, A32, CN, PO)                                                                                              \
     hipLaunchKernelGGL((place_fast_kernel<SLOTS, SET_BITS, ST, A32, CN, PO>), grid, block, smem, stream, db, prm, d_bases, d_offsets, \
                        lst, counts + c, ln, xc, d_out, d_stats, ac, profile_stop)
