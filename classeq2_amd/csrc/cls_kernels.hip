@@ -1028,7 +1028,13 @@ template <int SLOTS, int SET_BITS, bool STATS, bool ADDR32, bool CANON, bool POL
 __device__ __forceinline__ void place_read_fast(const DbDev& db, const PlaceParams& prm, const FastCtx& cx,
                                                 const uint8_t* __restrict__ bases, uint64_t b0, uint64_t b1, uint32_t r,
                                                 cls_placement* __restrict__ out, cls_query_stats* __restrict__ stats,
-                                                uint32_t profile_stop) {
+                                                uint32_t profile_stop_arg) {
+#ifdef CLS_PROFILE_HOOKS
+    const uint32_t profile_stop = profile_stop_arg;  // CLS_PROFILE_STOP=1|2: truncate after a phase (timing breakdowns)
+#else
+    constexpr uint32_t profile_stop = 0;  // (one less live scalar in a kernel that spills SGPRs)
+    (void)profile_stop_arg;
+#endif
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t k = db.k;
     const uint64_t L64 = b1 - b0;
@@ -1339,33 +1345,28 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, SLOTS <= 5 ? FAST_MIN_WAVES :
     cx.ccnt = cx.gcnt + (1u << SET_BITS);
     cx.conly = cx.ccnt + FAST_MAX_ARITY;
     cx.cpre = cx.conly + FAST_MAX_ARITY;
-    if (xcd_chunks) {
-        // locality-ordered list: XCD x (workgroups with blockIdx % 8 == x share an L2) walks the x-th
-        // eighth of the list front to back, so that reads processed together share cache lines
-        if (SLOTS > FAST_SLOTS_NARROW && *list_len == 0) return;  // no read of the wide class in the batch (the list holds every class)
-        const uint32_t n_list = list_n;
-        const uint32_t xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3, bpx = gridDim.x >> 3;
-        const uint32_t chunk = (n_list + 7u) >> 3;
-        const uint32_t cap = 64 * SLOTS;
-        for (uint32_t ql = slot * WAVES_PER_BLOCK + wave; ql < chunk; ql += bpx * WAVES_PER_BLOCK) {
-            const uint32_t q = xcd * chunk + ql;
-            if (q >= n_list) break;
-            const uint32_t r = list[q];
-            const uint64_t b0 = offsets[r], b1 = offsets[r + 1];
+    // Two walks over the class list, one call site (the body is large):
+    //  * locality-ordered list: XCD x (workgroups with blockIdx % 8 == x share an L2) walks the x-th eighth of
+    //    the list front to back, so that reads processed together share cache lines; the list holds every class
+    //  * plain class list: wave w takes entries w, w + n_waves, ...
+    if (xcd_chunks && SLOTS > FAST_SLOTS_NARROW && *list_len == 0) return;  // no read of the wide class in the batch
+    const uint32_t n_list = xcd_chunks ? list_n : *list_len;
+    const uint32_t xcd = blockIdx.x & 7u, bpx = gridDim.x >> 3;
+    const uint32_t chunk = xcd_chunks ? (n_list + 7u) >> 3 : n_list;
+    const uint32_t first = xcd_chunks ? (blockIdx.x >> 3) * WAVES_PER_BLOCK + wave : blockIdx.x * WAVES_PER_BLOCK + wave;
+    const uint32_t stride = (xcd_chunks ? bpx : gridDim.x) * WAVES_PER_BLOCK;
+    const uint32_t origin = xcd_chunks ? xcd * chunk : 0u;
+    constexpr uint32_t cap = 64 * SLOTS;
+    for (uint32_t ql = first; ql < chunk; ql += stride) {
+        const uint32_t q = origin + ql;
+        if (q >= n_list) break;
+        const uint32_t r = list[q];
+        const uint64_t b0 = offsets[r], b1 = offsets[r + 1];
+        if (xcd_chunks) {
             const uint64_t L64 = b1 - b0;
             if (L64 >= db.k && 2 * (L64 - db.k + 1) > cap) continue;  // another class' read (classify_kernel binned it)
             if (SLOTS > FAST_SLOTS_NARROW && (L64 < db.k || 2 * (L64 - db.k + 1) <= 64 * FAST_SLOTS_NARROW)) continue;
-            place_read_fast<SLOTS, SET_BITS, STATS, ADDR32, CANON, POLY>(db, prm, cx, bases, b0, b1, r, out, stats, profile_stop);
-            wave_sync();
         }
-        return;
-    }
-    const uint32_t gw = blockIdx.x * WAVES_PER_BLOCK + wave;
-    const uint32_t n_waves = gridDim.x * WAVES_PER_BLOCK;
-    const uint32_t n_list = *list_len;
-    for (uint32_t i = gw; i < n_list; i += n_waves) {
-        const uint32_t r = list[i];
-        const uint64_t b0 = offsets[r], b1 = offsets[r + 1];
         place_read_fast<SLOTS, SET_BITS, STATS, ADDR32, CANON, POLY>(db, prm, cx, bases, b0, b1, r, out, stats, profile_stop);
         wave_sync();
     }
