@@ -1259,8 +1259,6 @@ __device__ __forceinline__ void place_read_fast(const DbDev& db, const PlacePara
             continue;
         }
         const uint32_t a0 = P.s[0] + 1, a1 = P.s[6];  // first child = [a0, a1), second = [a1, end of the parent)
-        // both children's records, requested ahead of the counting
-        const snode_t CA = load_node(db.nodes, fc), CB = load_node(db.nodes, fc + 1);
         uint32_t c3 = 0, c3b = 0;  // per lane: k-mers in a | in b << 10 | in both << 20
         auto count = [&](uint32_t lo_, uint32_t hi_, uint32_t w) {
             const uint32_t ina = lo_ < a1 ? w : 0u;    // lo >= a0 for an active set, MAX for an inactive one
@@ -1293,7 +1291,7 @@ __device__ __forceinline__ void place_read_fast(const DbDev& db, const PlacePara
             return;
         }
         const bool right = only_b > only_a;
-        P = right ? CB : CA;
+        P = load_node(db.nodes, fc + (right ? 1u : 0u));  // (a speculative load of both children was sunk below the tie test by the compiler anyway)
         if (P.s[3] == 0) {  // no non-LEAF child below the chosen clade (update_introspection_node.rs:45-85)
             const uint32_t cn = right ? cnt_b : cnt_a, on = right ? only_b : only_a;
             write_record(out, r, CLS_IDENTITY_FOUND, (int32_t)(rm ? on : cn), (int32_t)(rm ? U - cn : U - on), (uint32_t)iteration,
