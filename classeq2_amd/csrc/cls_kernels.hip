@@ -1374,7 +1374,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, SLOTS <= 5 ? FAST_MIN_WAVES :
 // most specific one (fewest tips; ties: smaller first tip, then smaller record offset) names a leaf
 // neighbourhood (its first tip) and, through its record offset, a group of overlapping reads.
 // Reads the fast kernel will not place (too short / too long / bad characters) get the last key.
-template <int SLOTS, bool ADDR32>
+template <int SLOTS, bool ADDR32, bool FWD>
 __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void order_key_kernel(DbDev db, const uint8_t* __restrict__ bases,
                                                                        const uint64_t* __restrict__ offsets, uint32_t n_reads,
                                                                        uint64_t* __restrict__ keys, uint32_t* __restrict__ idx,
@@ -1400,11 +1400,12 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void order_key_kernel(DbDev d
             // reads of the next class (up to key_cap k-mers) are keyed by their first 32*SLOTS windows: the same
             // sorted list then orders both wave-per-read kernels
             const uint32_t L = (uint32_t)std::min<uint64_t>(L64, 32 * SLOTS + db.k - 1), nf = L - db.k + 1, nk = 2 * nf;
-            uint4 ent[SLOTS];
-            uint32_t kw[SLOTS];
+            constexpr int LS = FWD ? (SLOTS + 1) / 2 : SLOTS;  // one lookup per window needs half the slots
+            uint4 ent[LS];
+            uint32_t kw[LS];
             // one lookup per window, of the smaller of the k-mer and its reverse complement: an index built from
             // both strands files the two under the same leaves, and the key then does not depend on the strand read
-            if (fast_front<SLOTS, 0, ADDR32>(db, cx, bases, b0, L, nf, fwd_only ? nf : nk, ent, kw, sample_shift, fwd_only != 0)) {
+            if (fast_front<LS, 0, ADDR32>(db, cx, bases, b0, L, nf, FWD ? nf : nk, ent, kw, sample_shift, FWD)) {
                 // candidates: k-mers present in the index that are specific to a small clade (few tips);
                 // the tip bound is widened until a handful qualify (finally: every k-mer present)
                 uint32_t cand = 0, n_cand = 0;
@@ -1412,7 +1413,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void order_key_kernel(DbDev d
                 for (int tier = 0; tier < 4 && n_cand < 4; ++tier, lg_max = tier == 3 ? 31u : lg_max + 3u) {
                     cand = 0; n_cand = 0;
 #pragma unroll
-                    for (int s = 0; s < SLOTS; ++s) {
+                    for (int s = 0; s < LS; ++s) {
                         const bool c = ent[s].x != 0 && (ent[s].z >> DIRECT_TIP_BITS) <= lg_max;
                         cand |= (c ? 1u : 0u) << s;
                         n_cand += popc64(__ballot(c));
@@ -1425,7 +1426,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void order_key_kernel(DbDev d
                     for (int bit = (int)tip_bits - 1; bit >= 0; --bit) {
                         uint32_t c0 = 0;
 #pragma unroll
-                        for (int s = 0; s < SLOTS; ++s) {
+                        for (int s = 0; s < LS; ++s) {
                             const uint32_t t = ent[s].z & DIRECT_TIP_MASK;
                             const bool z = ((cand >> s) & 1u) && ((t ^ prefix) >> (bit + 1)) == 0 && !((t >> bit) & 1u);
                             c0 += popc64(__ballot(z));
@@ -1436,7 +1437,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void order_key_kernel(DbDev d
                     // reads that share most of their specific k-mers share it)
                     uint32_t mh = 0xFFFFFFFFu;
 #pragma unroll
-                    for (int s = 0; s < SLOTS; ++s) if ((cand >> s) & 1u) mh = ent[s].x < mh ? ent[s].x : mh;
+                    for (int s = 0; s < LS; ++s) if ((cand >> s) & 1u) mh = ent[s].x < mh ? ent[s].x : mh;
                     for (int o = 32; o > 0; o >>= 1) { const uint32_t other = __shfl_xor(mh, o); mh = other < mh ? other : mh; }
                     key = ((uint64_t)(prefix >> block_shift) << 32) | mh;
                 }
@@ -1961,7 +1962,7 @@ PlacePlan plan_place(const DbDev& db, uint32_t n_reads, uint32_t n_cu, bool stat
             int per_cu = forced_key;
             const uint32_t ac = ascii_cap_of(db, 0);
             const size_t smem_k = (size_t)WAVES_PER_BLOCK * (ac + 4u * (((ac >> 4) + 2 + 3) & ~3u) + 16u);
-            const void* kfn = db.addr32 ? (const void*)order_key_kernel<CLS_SLOTS[0], true> : (const void*)order_key_kernel<CLS_SLOTS[0], false>;
+            const void* kfn = db.addr32 ? (const void*)order_key_kernel<CLS_SLOTS[0], true, true> : (const void*)order_key_kernel<CLS_SLOTS[0], false, true>;
             if (per_cu <= 0 && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kfn, 64 * WAVES_PER_BLOCK, smem_k) != hipSuccess || per_cu <= 0)) per_cu = 4;
             p.grid_key = std::max<uint32_t>(1, std::min<uint32_t>(want, n_cu * (uint32_t)per_cu));
         }
@@ -2024,12 +2025,13 @@ hipError_t launch_place(const DbDev& db, const PlaceParams& prm, const PlacePlan
         static const uint32_t sample_shift = [] { const char* v = getenv("CLS_ORDER_SAMPLE_SHIFT"); return v ? (uint32_t)atoi(v) : 32u; }();
         static const uint32_t block_shift = [] { const char* v = getenv("CLS_ORDER_BLOCK_SHIFT"); return v ? (uint32_t)atoi(v) : 2u; }();
         const size_t smem_k = (size_t)WAVES_PER_BLOCK * (ac + 4u * (((ac >> 4) + 2 + 3) & ~3u) + 16u);
-        if (db.addr32)
-            hipLaunchKernelGGL((order_key_kernel<CLS_SLOTS[0], true>), dim3(plan.grid_key), dim3(64 * WAVES_PER_BLOCK), smem_k, stream, db,
-                               d_bases, d_offsets, n_reads, keys_in, idx_in, ac, tip_bits, spec_lg, block_shift, sample_shift, fwd_only, (uint32_t)(64 * CLS_SLOTS[1]));
-        else
-            hipLaunchKernelGGL((order_key_kernel<CLS_SLOTS[0], false>), dim3(plan.grid_key), dim3(64 * WAVES_PER_BLOCK), smem_k, stream, db,
-                               d_bases, d_offsets, n_reads, keys_in, idx_in, ac, tip_bits, spec_lg, block_shift, sample_shift, fwd_only, (uint32_t)(64 * CLS_SLOTS[1]));
+#define CLS_LAUNCH_KEY(A32, FW)                                                                                                       \
+    hipLaunchKernelGGL((order_key_kernel<CLS_SLOTS[0], A32, FW>), dim3(plan.grid_key), dim3(64 * WAVES_PER_BLOCK), smem_k, stream, db, \
+                       d_bases, d_offsets, n_reads, keys_in, idx_in, ac, tip_bits, spec_lg, block_shift, sample_shift, fwd_only,      \
+                       (uint32_t)(64 * CLS_SLOTS[1]))
+        if (db.addr32) { if (fwd_only) CLS_LAUNCH_KEY(true, true); else CLS_LAUNCH_KEY(true, false); }
+        else { if (fwd_only) CLS_LAUNCH_KEY(false, true); else CLS_LAUNCH_KEY(false, false); }
+#undef CLS_LAUNCH_KEY
         e = sort_pairs(d_ws + plan.sort_off_words, plan.sort_bytes, keys_in, keys_out, idx_in, idx_out, n_reads, ORDER_KEY_BITS, stream);
         if (e != hipSuccess) return e;
         list0 = idx_out;
