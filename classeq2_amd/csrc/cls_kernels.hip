@@ -1822,38 +1822,59 @@ __global__ __launch_bounds__(LONG_THREADS) void place_long_kernel(DbDev db, Plac
 // One thread per read: reads are binned by their k-mer count into the kernel wide enough for
 // them (class lists in device memory; nothing returns to the host).  Reads no kernel can hold
 // get their record here.
-__global__ void classify_kernel(const uint64_t* __restrict__ offsets, uint32_t n_reads, uint32_t k, uint32_t cap0,
-                                uint32_t cap1, uint32_t cap2, uint32_t cap3, uint32_t* __restrict__ list0,
-                                uint32_t* __restrict__ list1, uint32_t* __restrict__ list2, uint32_t* __restrict__ list3,
-                                uint32_t* __restrict__ counts, cls_placement* __restrict__ out,
-                                cls_query_stats* __restrict__ stats) {
-    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
-    int cls_id = -1;
-    if (r < n_reads) {
-        const uint64_t L = offsets[r + 1] - offsets[r];
-        const uint64_t nk = L < k ? 0 : 2 * (L - k + 1);
-        if (nk <= cap0) cls_id = 0;  // includes L < k: the kernel reports CLS_ERR_TOO_FEW_KMERS
-        else if (nk <= cap1) cls_id = 1;
-        else if (nk <= cap2) cls_id = 2;
-        else if (nk <= cap3) cls_id = 3;  // cap3 = 0: no long-read class in this launch
-        else {
-            uint64_t* o = reinterpret_cast<uint64_t*>(out + r);
-            o[0] = CLS_ERR_READ_TOO_LONG; o[1] = 0; o[2] = 0;
-            if (stats) {
-                uint64_t* st = reinterpret_cast<uint64_t*>(stats + r);
-                st[0] = nk > 0xFFFFFFFFull ? 0xFFFFFFFFull : nk; st[1] = 0; st[2] = 0;
+constexpr int CLASSIFY_THREADS = 256, CLASSIFY_PER_THREAD = 4;
+__global__ __launch_bounds__(CLASSIFY_THREADS) void classify_kernel(const uint64_t* __restrict__ offsets, uint32_t n_reads, uint32_t k,
+                                                                   uint32_t cap0, uint32_t cap1, uint32_t cap2, uint32_t cap3,
+                                                                   uint32_t* __restrict__ list0, uint32_t* __restrict__ list1,
+                                                                   uint32_t* __restrict__ list2, uint32_t* __restrict__ list3,
+                                                                   uint32_t* __restrict__ counts, cls_placement* __restrict__ out,
+                                                                   cls_query_stats* __restrict__ stats) {
+    // a workgroup bins 1024 reads: positions inside the workgroup from LDS counters, ONE global atomic per class
+    __shared__ uint32_t s_cnt[4], s_base[4];
+    if (threadIdx.x < 4) s_cnt[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t first = blockIdx.x * (CLASSIFY_THREADS * CLASSIFY_PER_THREAD) + threadIdx.x;
+    int cls_id[CLASSIFY_PER_THREAD];
+    uint32_t pos[CLASSIFY_PER_THREAD];
+#pragma unroll
+    for (int i = 0; i < CLASSIFY_PER_THREAD; ++i) {
+        const uint32_t r = first + i * CLASSIFY_THREADS;
+        cls_id[i] = -1;
+        pos[i] = 0;
+        if (r < n_reads) {
+            const uint64_t L = offsets[r + 1] - offsets[r];
+            const uint64_t nk = L < k ? 0 : 2 * (L - k + 1);
+            if (nk <= cap0) cls_id[i] = 0;  // includes L < k: the kernel reports CLS_ERR_TOO_FEW_KMERS
+            else if (nk <= cap1) cls_id[i] = 1;
+            else if (nk <= cap2) cls_id[i] = 2;
+            else if (nk <= cap3) cls_id[i] = 3;  // cap3 = 0: no long-read class in this launch
+            else {
+                uint64_t* o = reinterpret_cast<uint64_t*>(out + r);
+                o[0] = CLS_ERR_READ_TOO_LONG; o[1] = 0; o[2] = 0;
+                if (stats) {
+                    uint64_t* st = reinterpret_cast<uint64_t*>(stats + r);
+                    st[0] = nk > 0xFFFFFFFFull ? 0xFFFFFFFFull : nk; st[1] = 0; st[2] = 0;
+                }
             }
         }
-    }
-    const uint32_t lane = threadIdx.x & 63;
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        const uint64_t m = __ballot(cls_id == c);
-        if (!m) continue;
-        uint32_t base = 0;
-        if (lane == 0) base = atomicAdd(&counts[c], (uint32_t)__popcll(m));
-        base = __shfl(base, 0);
-        if (cls_id == c) (c == 0 ? list0 : c == 1 ? list1 : c == 2 ? list2 : list3)[base + __popcll(m & ((1ull << lane) - 1))] = r;
+        for (int c = 0; c < 4; ++c) {
+            const uint64_t m = __ballot(cls_id[i] == c);
+            if (!m) continue;
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(&s_cnt[c], (uint32_t)__popcll(m));
+            base = __shfl(base, 0);
+            if (cls_id[i] == c) pos[i] = base + (uint32_t)__popcll(m & ((1ull << lane) - 1));
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 4) s_base[threadIdx.x] = s_cnt[threadIdx.x] ? atomicAdd(&counts[threadIdx.x], s_cnt[threadIdx.x]) : 0u;
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < CLASSIFY_PER_THREAD; ++i) {
+        const int c = cls_id[i];
+        if (c >= 0) (c == 0 ? list0 : c == 1 ? list1 : c == 2 ? list2 : list3)[s_base[c] + pos[i]] = first + i * CLASSIFY_THREADS;
     }
 }
 
@@ -2001,7 +2022,7 @@ hipError_t launch_place(const DbDev& db, const PlaceParams& prm, const PlacePlan
     uint32_t* child_ws = (child_ws_stride(db) && !child_in_lds(db)) ? d_ws + plan.child_off_words : nullptr;
     hipError_t e = hipMemsetAsync(counts, 0, 64, stream);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(classify_kernel, dim3((n_reads + 255) / 256), dim3(256), 0, stream, d_offsets, n_reads, db.k,
+    hipLaunchKernelGGL(classify_kernel, dim3((n_reads + CLASSIFY_THREADS * CLASSIFY_PER_THREAD - 1) / (CLASSIFY_THREADS * CLASSIFY_PER_THREAD)), dim3(CLASSIFY_THREADS), 0, stream, d_offsets, n_reads, db.k,
                        (uint32_t)(64 * CLS_SLOTS[0]), (uint32_t)(64 * CLS_SLOTS[1]), (uint32_t)(64 * BLK_WAVES * BLK_SLOTS), plan.long_cap,
                        lists[0], lists[1], lists[2], lists[3], counts, d_out, d_stats);
     // CLS_PROFILE_STOP=1|2 truncates the split kernel after the match / state-init phase (timing
