@@ -152,6 +152,8 @@ extern "C" int cls_db_create(const cls_db_desc* d, int device, cls_db** out) {
         v.format = E.format;
         v.binary_tree = E.strictly_binary ? 1u : 0u;
         v.canonical = E.canonical ? 1u : 0u;
+        v.hdr_bits = 1;
+        while (v.hdr_bits < 32 && (1ull << v.hdr_bits) <= (uint64_t)cls::SPLIT_FIRST_REC + cls::SPLIT_HEADER_RECS * E.n_kmers) ++v.hdr_bits;
         v.addr32 = (E.postings.size() * 4 < (1ull << 32) && E.direct.size() * 4 < (1ull << 32)) ? 1u : 0u;
         cls_db_info& i = db->info;
         i.n_nodes = v.n_nodes;

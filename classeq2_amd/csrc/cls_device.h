@@ -110,7 +110,7 @@ struct DbDev {
     uint32_t addr32;     // postings and direct table are both below 4 GiB: 32-bit byte offsets suffice
     uint32_t binary_tree; // every clade has exactly zero or two children
     uint32_t canonical;   // direct table: every k-mer and its reverse complement hold the same entry state (index built from both strands)
-    uint32_t pad_;
+    uint32_t hdr_bits;    // FMT_SPLIT: bits that hold any k-mer's header record offset (the sort key of the locality order)
 };
 
 // Resolved Option<> arguments (place_sequence.rs:64-75)

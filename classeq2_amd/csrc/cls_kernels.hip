@@ -1439,7 +1439,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void order_key_kernel(DbDev d
 #pragma unroll
                     for (int s = 0; s < LS; ++s) if ((cand >> s) & 1u) mh = ent[s].x < mh ? ent[s].x : mh;
                     for (int o = 32; o > 0; o >>= 1) { const uint32_t other = __shfl_xor(mh, o); mh = other < mh ? other : mh; }
-                    key = ((uint64_t)(prefix >> block_shift) << 32) | mh;
+                    key = ((uint64_t)(prefix >> block_shift) << db.hdr_bits) | mh;  // as few key bits as the index needs: fewer radix passes
                 }
             }
             wave_sync();
@@ -1883,7 +1883,12 @@ __global__ __launch_bounds__(CLASSIFY_THREADS) void classify_kernel(const uint64
 namespace {
 constexpr int N_CLASSES = 2;            // wave-per-read classes; class 2 = one workgroup per read
 constexpr int BLK_WAVES = 8, BLK_SLOTS = 16, BLK_SET_BITS = 14;  // 8192 k-mers per read
-constexpr int ORDER_KEY_BITS = 32 + DIRECT_TIP_BITS;  // {first tip, record offset}
+constexpr int ORDER_KEY_BITS_MAX = 32 + DIRECT_TIP_BITS;  // {first tip, record offset}
+int order_key_bits(const DbDev& db) {  // + 1: reads without a key sort last with the all-ones key
+    uint32_t tip_bits = 1;
+    while (tip_bits < 32 && (1u << tip_bits) < db.n_nodes) ++tip_bits;
+    return std::min<int>(64, (int)(tip_bits + db.hdr_bits) + 1);
+}
 constexpr int CLS_SLOTS[N_CLASSES] = {5, 16};      // k-mers per read: 320 / 1024
 constexpr int CLS_SET_BITS[N_CLASSES] = {9, 11};   // LDS distinct-hit set: 512 / 2048 entries
 
@@ -1990,7 +1995,7 @@ PlacePlan plan_place(const DbDev& db, uint32_t n_reads, uint32_t n_cu, bool stat
         p.keys_off_words = w;
         w += 6 * (uint64_t)n_reads;
         p.sort_off_words = w;
-        p.sort_bytes = sort_temp_bytes(n_reads, ORDER_KEY_BITS);
+        p.sort_bytes = sort_temp_bytes(n_reads, ORDER_KEY_BITS_MAX + 5);
         w += (p.sort_bytes + 3) / 4 + 2;
         w += w & 1;
     }
@@ -2053,7 +2058,7 @@ hipError_t launch_place(const DbDev& db, const PlaceParams& prm, const PlacePlan
         if (db.addr32) { if (fwd_only) CLS_LAUNCH_KEY(true, true); else CLS_LAUNCH_KEY(true, false); }
         else { if (fwd_only) CLS_LAUNCH_KEY(false, true); else CLS_LAUNCH_KEY(false, false); }
 #undef CLS_LAUNCH_KEY
-        e = sort_pairs(d_ws + plan.sort_off_words, plan.sort_bytes, keys_in, keys_out, idx_in, idx_out, n_reads, ORDER_KEY_BITS, stream);
+        e = sort_pairs(d_ws + plan.sort_off_words, plan.sort_bytes, keys_in, keys_out, idx_in, idx_out, n_reads, order_key_bits(db), stream);
         if (e != hipSuccess) return e;
         list0 = idx_out;
         list0_n = n_reads;
