@@ -65,6 +65,7 @@ struct cls_db {
     void* d_postings = nullptr;
     void* d_bucket_key = nullptr;
     void* d_direct = nullptr;
+    void* d_ftable = nullptr;
     std::mutex ws_mu;
     uint64_t max_read_len = 16384;  // what the device-buffer entry provisions its long-read slices for
     double kernel_ms_sum = 0.0;
@@ -99,6 +100,7 @@ extern "C" void cls_db_destroy(cls_db* db) {
     if (db->d_postings) (void)hipFree(db->d_postings);
     if (db->d_bucket_key) (void)hipFree(db->d_bucket_key);
     if (db->d_direct) (void)hipFree(db->d_direct);
+    if (db->d_ftable) (void)hipFree(db->d_ftable);
     if (have_prev) (void)hipSetDevice(prev);
     delete db;
 }
@@ -133,7 +135,8 @@ extern "C" int cls_db_create(const cls_db_desc* d, int device, cls_db** out) {
             (e = up(&db->d_table, E.table.data(), E.table.size() * sizeof(cls::Slot))) != hipSuccess ||
             (e = up(&db->d_postings, E.postings.data(), E.postings.size() * 4)) != hipSuccess ||
             (e = up(&db->d_bucket_key, E.bucket_key.data(), E.bucket_key.size() * 8)) != hipSuccess ||
-            (!E.direct.empty() && (e = up(&db->d_direct, E.direct.data(), E.direct.size() * 4)) != hipSuccess)) {
+            (!E.direct.empty() && (e = up(&db->d_direct, E.direct.data(), E.direct.size() * 4)) != hipSuccess) ||
+            (!E.ftable.empty() && (e = up(&db->d_ftable, E.ftable.data(), E.ftable.size() * sizeof(cls::FSlot))) != hipSuccess)) {
             cls_db_destroy(db);
             return fail(e == hipErrorOutOfMemory ? CLS_E_NOMEM : CLS_E_HIP, std::string("cls_db_create: upload failed: ") + hipGetErrorString(e));
         }
@@ -143,6 +146,7 @@ extern "C" int cls_db_create(const cls_db_desc* d, int device, cls_db** out) {
         v.postings = (const uint32_t*)db->d_postings;
         v.bucket_key = (const uint64_t*)db->d_bucket_key;
         v.direct = (const uint32_t*)db->d_direct;
+        v.ftable = (const cls::FSlot*)db->d_ftable;
         v.table_mask = E.table.size() - 1;
         v.n_nodes = (uint32_t)E.nodes.size();
         v.n_buckets = (uint32_t)E.bucket_key.size();
@@ -166,7 +170,7 @@ extern "C" int cls_db_create(const cls_db_desc* d, int device, cls_db** out) {
         i.n_closed_kmers = E.n_closed;
         i.table_slots = E.table.size();
         i.postings_words = E.postings.size();
-        i.hbm_bytes = E.nodes.size() * sizeof(cls::DNode) + E.table.size() * sizeof(cls::Slot) + E.postings.size() * 4 + E.bucket_key.size() * 8 + E.direct.size() * 4;
+        i.hbm_bytes = E.nodes.size() * sizeof(cls::DNode) + E.table.size() * sizeof(cls::Slot) + E.postings.size() * 4 + E.bucket_key.size() * 8 + E.direct.size() * 4 + E.ftable.size() * sizeof(cls::FSlot);
         i.max_read_kmers = (uint32_t)std::max<uint64_t>(cls::MAX_READ_KMERS, 2 * db->max_read_len);
         i.device = device;
         i.format = E.format;

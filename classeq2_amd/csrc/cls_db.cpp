@@ -433,6 +433,28 @@ int encode_db(const cls_db_desc* d, EncodedDb& E, std::string& err) {
             E.canonical = !asym.load();
         }
     }
+    // ---- 7. without a direct table: the hash table once more, with the descent state inside the slots -----
+    if (E.format == FMT_SPLIT && E.direct.empty() && N < DIRECT_TIP_MASK && E.postings.size() * 4 < (1ULL << 32)) {
+        E.ftable.assign(cap, FSlot{0, 0, 0, 0xFFFFFFFFu, 0, 0, 0});
+        parallel_chunks(cap, nt, [&](unsigned, uint64_t lo, uint64_t hi) {
+            for (uint64_t i = lo; i < hi; ++i) {
+                const Slot& sl = E.table[i];
+                if (sl.loc == SLOT_EMPTY) continue;
+                const uint32_t off = (uint32_t)(sl.loc >> LOC_BUCKET_BITS);
+                const uint32_t* hd = &E.postings[(size_t)off * 4];  // {n | flags, root split, first tip, last tip}
+                const uint32_t n_tips = hd[0] & POST_LEN_MASK;
+                uint32_t lg = 0;
+                while (lg < 31 && (1u << lg) <= n_tips) ++lg;
+                FSlot& f = E.ftable[i];
+                f.hash = sl.hash;
+                f.off = off;
+                f.x = hd[1];
+                f.vlo_lg = n_tips ? ((lg << DIRECT_TIP_BITS) | hd[2]) : 0xFFFFFFFFu;
+                f.vhi_root = (n_tips ? hd[3] : 0u) | ((hd[0] & POST_HAS_ROOT) ? 0x80000000u : 0u);
+                f.bucket = (uint32_t)(sl.loc & LOC_BUCKET_MASK);
+            }
+        });
+    }
     E.bucket_key.assign(d->bucket_key, d->bucket_key + d->n_buckets);
     if (E.bucket_key.empty()) E.bucket_key.push_back(0);
     E.k = (uint32_t)d->k_size;

@@ -17,6 +17,7 @@ struct EncodedDb {
     bool strictly_binary = false;
     bool canonical = false;           // direct table symmetric under reverse complement
     std::vector<uint64_t> bucket_key;
+    std::vector<FSlot> ftable;        // FMT_SPLIT without a direct table: hash table slots that carry the descent state
     std::vector<uint32_t> direct;     // 4^k x {record offset, meta} (FMT_SPLIT, k <= DIRECT_MAX_K) or empty
     uint32_t k = 0, m = 0, m_eff = 0;
     uint32_t max_depth = 0, max_nonleaf_arity = 0;

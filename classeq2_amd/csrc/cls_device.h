@@ -34,6 +34,22 @@ struct Slot {
 };
 static_assert(sizeof(Slot) == 16, "Slot");
 constexpr uint64_t SLOT_EMPTY = ~0ULL;
+// The same table with the k-mer's initial descent state inside the slot (FMT_SPLIT without a direct table, i.e.
+// k > 15): a hit needs no header read.  Same capacity, same probe sequence as `Slot`.
+//   off      header record of the k-mer (0 = empty slot)
+//   x        root split
+//   vlo_lg   first tip | bit_length(n_tips) << 27   (0xFFFFFFFF: no tip below the root)
+//   vhi_root last tip | has_root << 31
+struct FSlot {
+    uint64_t hash;
+    uint32_t off;
+    uint32_t x;
+    uint32_t vlo_lg;
+    uint32_t vhi_root;
+    uint32_t bucket;
+    uint32_t pad_;
+};
+static_assert(sizeof(FSlot) == 32, "FSlot");
 constexpr int LOC_BUCKET_BITS = 24;
 constexpr uint64_t LOC_BUCKET_MASK = (1ULL << LOC_BUCKET_BITS) - 1;
 
@@ -100,6 +116,7 @@ struct DbDev {
     const uint32_t* postings;   // FMT_LIST: u32 words; FMT_SPLIT: TipRec records (16-byte units)
     const uint64_t* bucket_key;
     const uint32_t* direct;     // 4^k entries of 4 words (above) or nullptr
+    const FSlot* ftable;        // state-carrying hash table (above) or nullptr
     uint64_t table_mask;
     uint32_t n_nodes;
     uint32_t n_buckets;

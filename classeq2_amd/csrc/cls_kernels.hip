@@ -1024,7 +1024,100 @@ __device__ __forceinline__ bool fast_front(const DbDev& db, const FastCtx& cx, c
     return true;
 }
 
-template <int SLOTS, int SET_BITS, bool STATS, bool ADDR32, bool CANON, bool POLY>
+// MurmurHash3_x64_128(p[0..len), seed 0).0 with the message fetched eight bytes at a time (gfx950 reads unaligned
+// 64-bit words from LDS in one ds_read_b64).  Reads up to 15 bytes past the message, inside the caller's LDS buffer.
+__device__ __forceinline__ uint64_t lds_u64(const uint8_t* p) { uint64_t v; __builtin_memcpy(&v, p, 8); return v; }
+__device__ __forceinline__ uint64_t murmur3_h1_lds(const uint8_t* p, uint32_t len) {
+    Mur3 m;
+    const uint32_t nblocks = len >> 4;
+#pragma unroll 1
+    for (uint32_t b = 0; b < nblocks; ++b) m.block(lds_u64(p + 16 * b), lds_u64(p + 16 * b + 8));
+    const uint32_t t = len & 15u;
+    const uint8_t* tail = p + 16 * nblocks;
+    uint64_t k1 = 0, k2 = 0;
+    if (t > 0) { k1 = lds_u64(tail); if (t < 8) k1 &= (1ull << (8 * t)) - 1; }
+    if (t > 8) { k2 = lds_u64(tail + 8) & ((1ull << (8 * (t - 8))) - 1); }
+    return m.finish(k1, k2, t, len);
+}
+
+// The same front for an index WITHOUT a direct table (k > 15: the reference's default is k = 35): the read goes to
+// LDS as forward ++ reverse-complement ASCII, each k-mer is keyed by MurmurHash3 (kmers_map.rs:157-159), probed in
+// the HBM hash table and passed through the minimizer-bucket filter (kmers_map.rs:295-297; the wave-wide search for a
+// foreign bucket's key is never taken for built indexes); the table's slots carry the same entry as the direct
+// table: {header offset, root split, first tip | bit length << 27, last tip | has_root << 31} (FSlot, cls_device.h).
+template <int SLOTS, int SET_BITS, bool ADDR32>
+__device__ __forceinline__ bool hash_front(const DbDev& db, const FastCtx& cx, const uint8_t* __restrict__ bases, uint64_t b0,
+                                           uint32_t L, uint32_t nf, uint32_t nk, uint4 (&ent)[SLOTS], uint32_t (&kw)[SLOTS],
+                                           uint32_t table_bits) {
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t k = db.k, m_eff = db.m_eff;
+    bool bad = false;
+#pragma unroll 1
+    for (uint32_t i = lane; i < L; i += 64) {
+        uint8_t c = bases[b0 + i];
+        if (c >= 'a' && c <= 'z') c -= 32;
+        bad |= !(c == 'A' || c == 'C' || c == 'G' || c == 'T');
+        cx.ascii[i] = c;
+        cx.ascii[2 * L - 1 - i] = c ^ ((c & 2) ? 0x04 : 0x15);  // A<->T, C<->G
+    }
+#pragma unroll 1
+    for (uint32_t i = lane; i < (1u << table_bits); i += 64) {
+        cx.set[i] = SET_EMPTY;
+        if (SET_BITS) { cx.gkey[i] = SET_EMPTY; cx.gcnt[i] = 0; }
+    }
+    if (__ballot(bad)) return false;
+    wave_sync();
+    const uint8_t* seq = cx.ascii;
+    auto kmer_start = [&](uint32_t j) -> const uint8_t* { return seq + (j < nf ? j : L + (j - nf)); };
+#pragma unroll
+    for (int s = 0; s < SLOTS; ++s) {
+        const uint32_t j = s * 64 + lane;
+        bool hit = false;
+        uint64_t mz = 0;
+        uint4 st = uint4{0u, 0u, 0xFFFFFFFFu, 0u};  // {off, root split, first tip | lg << 27, last tip | root << 31}
+        uint32_t bucket = 0;
+        if (j < nk) {
+            const uint64_t h = murmur3_h1_lds(kmer_start(j), k);
+            mz = murmur3_h1_lds(kmer_start(j), m_eff);  // the "minimizer": the hash of the first m characters (kmers_map.rs:10-13)
+            uint64_t idx = h & db.table_mask;
+            const uint4* __restrict__ ft = reinterpret_cast<const uint4*>(db.ftable);  // slot = {hash lo, hash hi, off, x}{vlo_lg, vhi_root, bucket, -}
+#pragma unroll 1
+            for (;;) {
+                const uint4 a = ft[2 * idx];
+                if (a.z == 0) break;  // empty slot
+                if ((((uint64_t)a.y << 32) | a.x) == h) {
+                    const uint4 b = ft[2 * idx + 1];
+                    hit = true;
+                    st = uint4{a.z, a.w, b.x, b.y};
+                    bucket = b.z;
+                    break;
+                }
+                idx = (idx + 1) & db.table_mask;
+            }
+        }
+        bool ok = false;
+        uint64_t bk = 0;
+        if (hit) { bk = db.bucket_key[bucket]; ok = (bk == mz); }
+        uint64_t pend = __ballot(hit && !ok);
+        while (pend) {  // the bucket's key may still be the minimizer of another query k-mer
+            const int src = __ffsll((unsigned long long)pend) - 1;
+            const uint64_t B = ((uint64_t)__shfl((uint32_t)(bk >> 32), src) << 32) | __shfl((uint32_t)bk, src);
+            bool f = false;
+#pragma unroll 1
+            for (uint32_t jj = lane; jj < 2 * nf; jj += 64) {  // every k-mer of the read, both strands
+                f |= murmur3_h1_lds(kmer_start(jj), m_eff) == B;
+            }
+            const bool any = __ballot(f) != 0;
+            if ((int)lane == src) ok = any;
+            pend &= pend - 1;
+        }
+        ent[s] = (hit && ok) ? st : uint4{0u, 0u, 0xFFFFFFFFu, 0u};
+        kw[s] = (hit && ok) ? 1u : 0u;
+    }
+    return true;
+}
+
+template <int SLOTS, int SET_BITS, bool STATS, bool ADDR32, int MODE, bool POLY>
 __device__ __forceinline__ void place_read_fast(const DbDev& db, const PlaceParams& prm, const FastCtx& cx,
                                                 const uint8_t* __restrict__ bases, uint64_t b0, uint64_t b1, uint32_t r,
                                                 cls_placement* __restrict__ out, cls_query_stats* __restrict__ stats,
@@ -1052,6 +1145,7 @@ __device__ __forceinline__ void place_read_fast(const DbDev& db, const PlacePara
     // CANON (an index in which every k-mer and its reverse complement carry the same tip set, i.e. one built from
     // both strands): the k-mers of window p on the two strands are reverse complements of each other, so ONE lookup
     // of the smaller of the two answers for both; half the lookups, half the slots.
+    constexpr bool CANON = MODE == 1, HASHED = MODE == 2;  // MODE 0: direct table, both strands looked up
     constexpr int LS = CANON ? (SLOTS + 1) / 2 : SLOTS;
     uint4 ent[LS];
     uint32_t kw[LS];
@@ -1063,7 +1157,10 @@ __device__ __forceinline__ void place_read_fast(const DbDev& db, const PlacePara
         while ((1u << tb) < want && tb < (uint32_t)SET_BITS) ++tb;
         tb = uniform(tb);
     }
-    if (!fast_front<LS, SET_BITS, ADDR32>(db, cx, bases, b0, L, nf, CANON ? nf : nk, ent, kw, 32, CANON, tb)) {
+    bool valid_read;
+    if constexpr (HASHED) valid_read = hash_front<LS, SET_BITS, ADDR32>(db, cx, bases, b0, L, nf, nk, ent, kw, tb);
+    else valid_read = fast_front<LS, SET_BITS, ADDR32>(db, cx, bases, b0, L, nf, CANON ? nf : nk, ent, kw, 32, CANON, tb);
+    if (!valid_read) {
         put_stats(0, 0, 0, 0);
         write_record(out, r, CLS_ERR_INVALID_BASE, 0, 0, 0, 0);
         return;
@@ -1323,14 +1420,15 @@ __device__ __forceinline__ void place_read_fast(const DbDev& db, const PlacePara
     }
 }
 
-template <int SLOTS, int SET_BITS, bool STATS, bool ADDR32, bool CANON, bool POLY>
+template <int SLOTS, int SET_BITS, bool STATS, bool ADDR32, int MODE, bool POLY>
 __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, SLOTS <= 5 ? FAST_MIN_WAVES : FAST_MIN_WAVES_WIDE) void place_fast_kernel(
     DbDev db, PlaceParams prm, const uint8_t* __restrict__ bases, const uint64_t* __restrict__ offsets,
     const uint32_t* __restrict__ list, const uint32_t* __restrict__ list_len, uint32_t list_n, uint32_t xcd_chunks,
     cls_placement* __restrict__ out, cls_query_stats* __restrict__ stats, uint32_t ascii_cap, uint32_t profile_stop) {
     extern __shared__ __align__(16) uint8_t smem[];
     const uint32_t wave = threadIdx.x >> 6;
-    const uint32_t packed_words = ((ascii_cap >> 4) + 2 + 3) & ~3u;  // whole 16-byte units: what follows stays 16-byte aligned
+    // (MODE 2 keeps forward ++ reverse-complement ASCII in `ascii_cap` bytes and packs nothing)
+    const uint32_t packed_words = MODE == 2 ? 0u : ((ascii_cap >> 4) + 2 + 3) & ~3u;  // whole 16-byte units: what follows stays 16-byte aligned
     static_assert((12u << SET_BITS) >= 16u * 64 * SLOTS, "the staging area must fit over the three tables");
     const uint32_t per_wave = ascii_cap + 4u * packed_words + (12u << SET_BITS) + (POLY ? 12u * FAST_MAX_ARITY + 16u : 0u);
     FastCtx cx;
@@ -1365,7 +1463,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, SLOTS <= 5 ? FAST_MIN_WAVES :
             if (L64 >= db.k && 2 * (L64 - db.k + 1) > cap) continue;  // another class' read (classify_kernel binned it)
             if (SLOTS > FAST_SLOTS_NARROW && (L64 < db.k || 2 * (L64 - db.k + 1) <= 64 * FAST_SLOTS_NARROW)) continue;
         }
-        place_read_fast<SLOTS, SET_BITS, STATS, ADDR32, CANON, POLY>(db, prm, cx, bases, b0, b1, r, out, stats, profile_stop);
+        place_read_fast<SLOTS, SET_BITS, STATS, ADDR32, MODE, POLY>(db, prm, cx, bases, b0, b1, r, out, stats, profile_stop);
         wave_sync();
     }
 }
@@ -1374,7 +1472,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, SLOTS <= 5 ? FAST_MIN_WAVES :
 // most specific one (fewest tips; ties: smaller first tip, then smaller record offset) names a leaf
 // neighbourhood (its first tip) and, through its record offset, a group of overlapping reads.
 // Reads the fast kernel will not place (too short / too long / bad characters) get the last key.
-template <int SLOTS, bool ADDR32, bool FWD>
+template <int SLOTS, bool ADDR32, bool FWD, bool HASHED>
 __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void order_key_kernel(DbDev db, const uint8_t* __restrict__ bases,
                                                                        const uint64_t* __restrict__ offsets, uint32_t n_reads,
                                                                        uint64_t* __restrict__ keys, uint32_t* __restrict__ idx,
@@ -1383,7 +1481,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void order_key_kernel(DbDev d
                                                                        uint32_t key_cap) {
     extern __shared__ __align__(16) uint8_t smem[];
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const uint32_t packed_words = ((ascii_cap >> 4) + 2 + 3) & ~3u;  // whole 16-byte units: what follows stays 16-byte aligned
+    const uint32_t packed_words = HASHED ? 0u : ((ascii_cap >> 4) + 2 + 3) & ~3u;  // whole 16-byte units: what follows stays 16-byte aligned
     const uint32_t per_wave = ascii_cap + 4u * packed_words + 16u;
     FastCtx cx;
     cx.ascii = smem + wave * per_wave;
@@ -1405,7 +1503,11 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void order_key_kernel(DbDev d
             uint32_t kw[LS];
             // one lookup per window, of the smaller of the k-mer and its reverse complement: an index built from
             // both strands files the two under the same leaves, and the key then does not depend on the strand read
-            if (fast_front<LS, 0, ADDR32>(db, cx, bases, b0, L, nf, FWD ? nf : nk, ent, kw, sample_shift, FWD)) {
+            bool valid_read;
+            // (without a direct table FWD means "the forward k-mers only": the key then depends on the strand read)
+            if constexpr (HASHED) valid_read = hash_front<LS, 0, ADDR32>(db, cx, bases, b0, L, nf, FWD ? nf : nk, ent, kw, 0);
+            else valid_read = fast_front<LS, 0, ADDR32>(db, cx, bases, b0, L, nf, FWD ? nf : nk, ent, kw, sample_shift, FWD);
+            if (valid_read) {
                 // candidates: k-mers present in the index that are specific to a small clade (few tips);
                 // the tip bound is widened until a handful qualify (finally: every k-mer present)
                 uint32_t cand = 0, n_cand = 0;
@@ -1899,18 +2001,25 @@ bool use_order(const DbDev& db, uint32_t n_reads) {
 }
 bool use_fast(const DbDev& db) {
     static const bool off = getenv("CLS_NO_FAST") != nullptr;  // A/B experiments
-    return db.format == FMT_SPLIT && (db.binary_tree || db.max_nonleaf_arity <= FAST_MAX_ARITY) && db.direct != nullptr && !off;
+    // with a direct table (k <= 15), or keyed by MurmurHash3 through the hash table (pre-order indices must fit the entry)
+    const bool front = db.direct != nullptr || (db.ftable != nullptr && db.addr32 && db.k <= 256);
+    return db.format == FMT_SPLIT && (db.binary_tree || db.max_nonleaf_arity <= FAST_MAX_ARITY) && front && !off;
 }
+int fast_mode(const DbDev& db) { return db.direct == nullptr ? 2 : db.canonical ? 1 : 0; }
 uint32_t seq_cap_of(const DbDev& db, int c) { return (2 * (64 * CLS_SLOTS[c] / 2 + db.k) + 15) & ~15u; }
 // fast path: L <= 32*SLOTS + k - 1 ascii bytes (+ padding so that the 16-byte packer can over-read)
-uint32_t ascii_cap_of(const DbDev& db, int c) { return (64 * CLS_SLOTS[c] / 2 + db.k + 16 + 15) & ~15u; }
+uint32_t ascii_cap_of(const DbDev& db, int c) {
+    const uint32_t fwd = 64 * CLS_SLOTS[c] / 2 + db.k + 16;
+    return ((db.direct ? fwd : 2 * fwd) + 15) & ~15u;  // without a direct table: forward ++ reverse complement, hashed as ASCII
+}
 uint32_t child_ws_stride(const DbDev& db);
 constexpr uint32_t CHILD_LDS_MAX = 256;  // per-child counters of polytomies up to this arity live in LDS
 bool child_in_lds(const DbDev& db) { return child_ws_stride(db) != 0 && child_ws_stride(db) <= CHILD_LDS_MAX; }
 size_t smem_of(const DbDev& db, int c) {
     if (use_fast(db)) {
         const uint32_t ac = ascii_cap_of(db, c);
-        return (size_t)WAVES_PER_BLOCK * (ac + 4u * (((ac >> 4) + 2 + 3) & ~3u) + (12u << CLS_SET_BITS[c]) + (db.binary_tree ? 0u : 12u * FAST_MAX_ARITY + 16u));
+        const uint32_t packed = db.direct ? 4u * (((ac >> 4) + 2 + 3) & ~3u) : 0u;
+        return (size_t)WAVES_PER_BLOCK * (ac + packed + (12u << CLS_SET_BITS[c]) + (db.binary_tree ? 0u : 12u * FAST_MAX_ARITY + 16u));
     }
     return (size_t)WAVES_PER_BLOCK * (seq_cap_of(db, c) + (4u << CLS_SET_BITS[c]) + 4u * 64 * CLS_SLOTS[c]) +
            (child_in_lds(db) ? (size_t)WAVES_PER_BLOCK * 2 * child_ws_stride(db) * 4 : 0);
@@ -1919,10 +2028,12 @@ size_t smem_of(const DbDev& db, int c) {
 template <int SLOTS, int SET_BITS>
 const void* kernel_of_t(const DbDev& db, bool stats) {
     if (use_fast(db)) {
-#define CLS_FAST_OF(A32, CN, PO) (stats ? (const void*)place_fast_kernel<SLOTS, SET_BITS, true, A32, CN, PO> : (const void*)place_fast_kernel<SLOTS, SET_BITS, false, A32, CN, PO>)
-#define CLS_FAST_OF2(A32, CN) (db.binary_tree ? CLS_FAST_OF(A32, CN, false) : CLS_FAST_OF(A32, CN, true))
-        if (db.addr32) return db.canonical ? CLS_FAST_OF2(true, true) : CLS_FAST_OF2(true, false);
-        return db.canonical ? CLS_FAST_OF2(false, true) : CLS_FAST_OF2(false, false);
+#define CLS_FAST_OF(A32, MD, PO) (stats ? (const void*)place_fast_kernel<SLOTS, SET_BITS, true, A32, MD, PO> : (const void*)place_fast_kernel<SLOTS, SET_BITS, false, A32, MD, PO>)
+#define CLS_FAST_OF2(A32, MD) (db.binary_tree ? CLS_FAST_OF(A32, MD, false) : CLS_FAST_OF(A32, MD, true))
+        const int mode = fast_mode(db);
+        if (mode == 2) return CLS_FAST_OF2(true, 2);  // (the hashed front is only instantiated with 32-bit offsets: use_fast)
+        if (db.addr32) return mode == 1 ? CLS_FAST_OF2(true, 1) : CLS_FAST_OF2(true, 0);
+        return mode == 1 ? CLS_FAST_OF2(false, 1) : CLS_FAST_OF2(false, 0);
 #undef CLS_FAST_OF2
 #undef CLS_FAST_OF
     }
@@ -1987,8 +2098,9 @@ PlacePlan plan_place(const DbDev& db, uint32_t n_reads, uint32_t n_cu, bool stat
             static const int forced_key = [] { const char* e = getenv("CLS_KEY_BLOCKS_PER_CU"); return e ? atoi(e) : 0; }();
             int per_cu = forced_key;
             const uint32_t ac = ascii_cap_of(db, 0);
-            const size_t smem_k = (size_t)WAVES_PER_BLOCK * (ac + 4u * (((ac >> 4) + 2 + 3) & ~3u) + 16u);
-            const void* kfn = db.addr32 ? (const void*)order_key_kernel<CLS_SLOTS[0], true, true> : (const void*)order_key_kernel<CLS_SLOTS[0], false, true>;
+            const size_t smem_k = (size_t)WAVES_PER_BLOCK * (ac + (db.direct ? 4u * (((ac >> 4) + 2 + 3) & ~3u) : 0u) + 16u);
+            const void* kfn = fast_mode(db) == 2 ? (const void*)order_key_kernel<CLS_SLOTS[0], true, true, true>
+                              : db.addr32 ? (const void*)order_key_kernel<CLS_SLOTS[0], true, true, false> : (const void*)order_key_kernel<CLS_SLOTS[0], false, true, false>;
             if (per_cu <= 0 && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kfn, 64 * WAVES_PER_BLOCK, smem_k) != hipSuccess || per_cu <= 0)) per_cu = 4;
             p.grid_key = std::max<uint32_t>(1, std::min<uint32_t>(want, n_cu * (uint32_t)per_cu));
         }
@@ -2050,13 +2162,14 @@ hipError_t launch_place(const DbDev& db, const PlaceParams& prm, const PlacePlan
         static const uint32_t fwd_only = [] { const char* v = getenv("CLS_ORDER_BOTH_STRANDS"); return v ? 0u : 1u; }();
         static const uint32_t sample_shift = [] { const char* v = getenv("CLS_ORDER_SAMPLE_SHIFT"); return v ? (uint32_t)atoi(v) : 32u; }();
         static const uint32_t block_shift = [] { const char* v = getenv("CLS_ORDER_BLOCK_SHIFT"); return v ? (uint32_t)atoi(v) : 2u; }();
-        const size_t smem_k = (size_t)WAVES_PER_BLOCK * (ac + 4u * (((ac >> 4) + 2 + 3) & ~3u) + 16u);
-#define CLS_LAUNCH_KEY(A32, FW)                                                                                                       \
-    hipLaunchKernelGGL((order_key_kernel<CLS_SLOTS[0], A32, FW>), dim3(plan.grid_key), dim3(64 * WAVES_PER_BLOCK), smem_k, stream, db, \
-                       d_bases, d_offsets, n_reads, keys_in, idx_in, ac, tip_bits, spec_lg, block_shift, sample_shift, fwd_only,      \
+        const size_t smem_k = (size_t)WAVES_PER_BLOCK * (ac + (db.direct ? 4u * (((ac >> 4) + 2 + 3) & ~3u) : 0u) + 16u);
+#define CLS_LAUNCH_KEY(A32, FW, HS)                                                                                                       \
+    hipLaunchKernelGGL((order_key_kernel<CLS_SLOTS[0], A32, FW, HS>), dim3(plan.grid_key), dim3(64 * WAVES_PER_BLOCK), smem_k, stream, db, \
+                       d_bases, d_offsets, n_reads, keys_in, idx_in, ac, tip_bits, spec_lg, block_shift, sample_shift, fwd_only,          \
                        (uint32_t)(64 * CLS_SLOTS[1]))
-        if (db.addr32) { if (fwd_only) CLS_LAUNCH_KEY(true, true); else CLS_LAUNCH_KEY(true, false); }
-        else { if (fwd_only) CLS_LAUNCH_KEY(false, true); else CLS_LAUNCH_KEY(false, false); }
+        if (fast_mode(db) == 2) { if (fwd_only) CLS_LAUNCH_KEY(true, true, true); else CLS_LAUNCH_KEY(true, false, true); }
+        else if (db.addr32) { if (fwd_only) CLS_LAUNCH_KEY(true, true, false); else CLS_LAUNCH_KEY(true, false, false); }
+        else { if (fwd_only) CLS_LAUNCH_KEY(false, true, false); else CLS_LAUNCH_KEY(false, false, false); }
 #undef CLS_LAUNCH_KEY
         e = sort_pairs(d_ws + plan.sort_off_words, plan.sort_bytes, keys_in, keys_out, idx_in, idx_out, n_reads, order_key_bits(db), stream);
         if (e != hipSuccess) return e;
@@ -2073,12 +2186,13 @@ hipError_t launch_place(const DbDev& db, const PlaceParams& prm, const PlacePlan
             const uint32_t ac = ascii_cap_of(db, c);
             const uint32_t* lst = xcd_chunks ? list0 : lists[c];  // ordered: one list for both classes, each skips the other's reads
             const uint32_t ln = list0_n, xc = xcd_chunks;
-#define CLS_LAUNCH_FAST(ST, A32, CN, PO)                                                                                              \
-    hipLaunchKernelGGL((place_fast_kernel<SLOTS, SET_BITS, ST, A32, CN, PO>), grid, block, smem, stream, db, prm, d_bases, d_offsets, \
+#define CLS_LAUNCH_FAST(ST, A32, MD, PO)                                                                                              \
+    hipLaunchKernelGGL((place_fast_kernel<SLOTS, SET_BITS, ST, A32, MD, PO>), grid, block, smem, stream, db, prm, d_bases, d_offsets, \
                        lst, counts + c, ln, xc, d_out, d_stats, ac, profile_stop)
-#define CLS_LAUNCH_FAST3(ST, A32, CN) do { if (db.binary_tree) CLS_LAUNCH_FAST(ST, A32, CN, false); else CLS_LAUNCH_FAST(ST, A32, CN, true); } while (0)
-#define CLS_LAUNCH_FAST2(ST, A32) do { if (db.canonical) CLS_LAUNCH_FAST3(ST, A32, true); else CLS_LAUNCH_FAST3(ST, A32, false); } while (0)
-            if (db.addr32) { if (st) CLS_LAUNCH_FAST2(true, true); else CLS_LAUNCH_FAST2(false, true); }
+#define CLS_LAUNCH_FAST3(ST, A32, MD) do { if (db.binary_tree) CLS_LAUNCH_FAST(ST, A32, MD, false); else CLS_LAUNCH_FAST(ST, A32, MD, true); } while (0)
+#define CLS_LAUNCH_FAST2(ST, A32) do { if (db.canonical) CLS_LAUNCH_FAST3(ST, A32, 1); else CLS_LAUNCH_FAST3(ST, A32, 0); } while (0)
+            if (fast_mode(db) == 2) { if (st) CLS_LAUNCH_FAST3(true, true, 2); else CLS_LAUNCH_FAST3(false, true, 2); }
+            else if (db.addr32) { if (st) CLS_LAUNCH_FAST2(true, true); else CLS_LAUNCH_FAST2(false, true); }
             else { if (st) CLS_LAUNCH_FAST2(true, false); else CLS_LAUNCH_FAST2(false, false); }
 #undef CLS_LAUNCH_FAST2
 #undef CLS_LAUNCH_FAST3
