@@ -2122,7 +2122,9 @@ PlacePlan plan_place(const DbDev& db, uint32_t n_reads, uint32_t n_cu, bool stat
         p.long_arity = (std::max(db.max_nonleaf_arity, 1u) + 63) & ~63u;
         p.long_stride_words = 2 * (uint64_t)LONG_STATE_WORDS * long_cap + 2 * (uint64_t)p.long_arity;
         const uint64_t fit = std::max<uint64_t>(1, (2ull << 30) / (p.long_stride_words * 4));  // at most 2 GiB of slices
-        p.grid_long = (uint32_t)std::min<uint64_t>({(uint64_t)n_long, (uint64_t)n_cu, fit});
+        // the kernel is bound by the latency of dependent reads and uses little LDS / few registers: several reads per CU
+        static const uint64_t per_cu_long = [] { const char* e = getenv("CLS_LONG_BLOCKS_PER_CU"); return e ? (uint64_t)atoi(e) : 2ull; }();  // (1: 25.5 k reads/s of 10 kb, 2..8: 31 k)
+        p.grid_long = (uint32_t)std::min<uint64_t>({(uint64_t)n_long, (uint64_t)n_cu * per_cu_long, fit});
         p.long_off_words = w;
         w += p.long_stride_words * p.grid_long;
     }

@@ -5,10 +5,10 @@ import numpy as np
 from classeq2_amd import engine
 from classeq2_amd.synth import SynthDb
 k = int(sys.argv[1]) if len(sys.argv) > 1 else 15
+n = int(sys.argv[2]) if len(sys.argv) > 2 else 2000
 s = SynthDb(300, 12000, k, 4, deep=1)
 db = engine.PlacementDb(s.flat, device=0)
 print("depth", db.info.max_depth, "kmers", db.info.n_kmers, "direct", db.info.direct_table)
-n = 2000
 bases, offsets, _ = s.reads(n, 10000)
 db.place_batch(bases[:10000 * 50], offsets[:51])
 t = time.time(); out = db.place_batch(bases, offsets); dt = time.time() - t
