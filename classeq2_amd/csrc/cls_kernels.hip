@@ -1561,12 +1561,15 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void order_key_kernel(DbDev d
 constexpr int LONG_THREADS = 256;
 constexpr int LONG_STATE_WORDS = 5;  // u32 arrays per state buffer: SPLIT {vlo, vhi, x}; LIST {lo, hi, vlo, vhi, closed}
 
+constexpr uint32_t LONG_LDS_ARITY = 256;  // children intervals kept in LDS up to this many non-LEAF children
 struct LongSh {
     uint32_t acc[4];
     unsigned long long acc64;
     uint32_t n_next;     // survivors appended to the next state buffer
     uint32_t n_pass, n_best, best_row;
     int32_t best_diff, best_one, best_rest;
+    uint32_t cpre[LONG_LDS_ARITY + 1];  // where the current clade's non-LEAF children start (+ the end of the last)
+    uint32_t cnt_l[LONG_LDS_ARITY], only_l[LONG_LDS_ARITY];  // per-child counters of clades with at most that many
 };
 
 __device__ __forceinline__ uint32_t wave_sum(uint32_t v);
@@ -1783,14 +1786,24 @@ __global__ __launch_bounds__(LONG_THREADS) void place_long_kernel(DbDev db, Plac
             if (iteration > prm.max_iterations) { record(CLS_ERR_MAX_ITER, 0, 0, (uint32_t)iteration, 0); break; }
             const uint32_t fc = nodes[prow].first_child, m = nodes[prow].n_nonleaf;  // the non-LEAF children come first
             __syncthreads();
+            // per-child counters: in LDS for ordinary clades (hundreds of same-address atomics per level were serialising
+            // in L2), in the workspace slice for huge polytomies
+            uint32_t* const cntp = m <= LONG_LDS_ARITY ? sh.cnt_l : cnt;
+            uint32_t* const onlyp = m <= LONG_LDS_ARITY ? sh.only_l : only;
             for (uint32_t i = tid; i < m; i += NT) {
-                __hip_atomic_store(&cnt[i], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(&only[i], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&cntp[i], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&onlyp[i], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             if (tid == 0) { sh.n_pass = 0; sh.n_best = 0; sh.best_diff = 0; sh.n_next = 0; }
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
             __syncthreads();
             const uint32_t last_end = m ? nodes[fc + m - 1].pre + nodes[fc + m - 1].size : 0u;
+            const bool lds_children = m <= LONG_LDS_ARITY;  // the children tile [pre + 1, last_end) back to back
+            if (lds_children) {
+                for (uint32_t i = tid; i < m; i += NT) sh.cpre[i] = nodes[fc + i].pre;
+                if (tid == 0) sh.cpre[m] = last_end;
+                __syncthreads();
+            }
             uint32_t U = 0;
             // One atomic per wavefront and distinct child instead of one per k-mer: on a binary clade every k-mer of
             // the read votes for one of two counters, and 20 000 atomics on two addresses per level was the kernel.
@@ -1816,10 +1829,15 @@ __global__ __launch_bounds__(LONG_THREADS) void place_long_kernel(DbDev db, Plac
                         uint32_t lo_ = 0, c_end = 0;
                         if (walking) {
                             uint32_t hi_ = m;
-                            while (hi_ - lo_ > 1) { const uint32_t mid = (lo_ + hi_) >> 1; if (nodes[fc + mid].pre <= v) lo_ = mid; else hi_ = mid; }
-                            c_end = nodes[fc + lo_].pre + nodes[fc + lo_].size;
+                            if (lds_children) {
+                                while (hi_ - lo_ > 1) { const uint32_t mid = (lo_ + hi_) >> 1; if (sh.cpre[mid] <= v) lo_ = mid; else hi_ = mid; }
+                                c_end = sh.cpre[lo_ + 1];
+                            } else {
+                                while (hi_ - lo_ > 1) { const uint32_t mid = (lo_ + hi_) >> 1; if (nodes[fc + mid].pre <= v) lo_ = mid; else hi_ = mid; }
+                                c_end = nodes[fc + lo_].pre + nodes[fc + lo_].size;
+                            }
                         }
-                        add_grouped(cnt, walking, lo_);
+                        add_grouped(cntp, walking, lo_);
                         if (walking) {
                             if (nin == 0) which = lo_;
                             if (nin < 2) ++nin;
@@ -1840,20 +1858,20 @@ __global__ __launch_bounds__(LONG_THREADS) void place_long_kernel(DbDev db, Plac
                         const bool in = valid && member_of(post, lo, hi, vlo, vhi, closed, c0, c1);
                         const uint64_t mm = __ballot(in);
                         if (mm && lane == (uint32_t)(__ffsll((unsigned long long)mm) - 1))
-                            __hip_atomic_fetch_add(&cnt[ci], (uint32_t)__popcll(mm), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            __hip_atomic_fetch_add(&cntp[ci], (uint32_t)__popcll(mm), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         if (in) { if (nin == 0) which = ci; if (nin < 2) ++nin; }
                     }
                 }
-                add_grouped(only, nin == 1, which);
+                add_grouped(onlyp, nin == 1, which);
                 U += nin ? 1u : 0u;
             }
             { uint32_t v[1] = {U}; __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent"); long_sum<1>(v, sh); U = v[0]; }
             // (one, rest), place_sequence.rs:369-395, with |R_c| = |U| - |only_c| and |R_c \ K_c| = |U| - |K_c|
             for (int pass_no = 0; pass_no < 2; ++pass_no) {
                 for (uint32_t ci = tid; ci < m; ci += NT) {
-                    const uint32_t cn = __hip_atomic_load(&cnt[ci], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const uint32_t cn = __hip_atomic_load(&cntp[ci], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     if (!cn) continue;  // K_c empty: not a candidate (:329)
-                    const uint32_t on = __hip_atomic_load(&only[ci], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const uint32_t on = __hip_atomic_load(&onlyp[ci], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     const int32_t one = (int32_t)(rm ? on : cn), rest = (int32_t)(rm ? U - cn : U - on);
                     if (one <= rest) continue;  // :411-417
                     if (pass_no == 0) { atomicAdd(&sh.n_pass, 1u); atomicMax(&sh.best_diff, one - rest); }
