@@ -148,6 +148,19 @@ def test_ladder_tree_deeper_than_the_iteration_cap(k, collapse):
         assert got5k["levels"].max() > 1050 and (got5k["status"] != _abi.ERR_MAX_ITER).all()
 
 
+@pytest.mark.parametrize("k,collapse,trunc", [(21, 0.0, False), (35, 0.3, False), (12, 0.3, False), (12, 0.0, True), (19, 0.0, True)])
+def test_large_batches_take_the_locality_ordered_path(k, collapse, trunc):
+    """>= 4096 reads: the key kernel + sort + XCD-ordered walk, for both wave-per-read classes (reads of 60..480 bp),
+    with the direct table (k <= 15: strand-symmetric and not) and with the MurmurHash3 front (k > 15)."""
+    s = SynthDb(300, 900, k, 4, collapse_prob=collapse)
+    flat = truncate_random_sets(s.flat, 0.05, seed=6) if trunc else s.flat
+    rng = np.random.default_rng(17)
+    bases, offsets = ragged_reads(rng, s, 6000, 60, 480, lower_frac=0.02)
+    assert len(offsets) - 1 >= 4096
+    for kw in (dict(), dict(remove_intersection=True)):
+        _check(flat, bases, offsets, kw, threads=16)
+
+
 def test_long_and_short_reads_in_one_batch():
     """One batch through all four kernels (320 / 1024 / 8192 k-mers and the workspace kernel), an invalid base
     in a long read, and a long read of random bases."""
