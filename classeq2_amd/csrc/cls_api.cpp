@@ -37,6 +37,8 @@ struct Workspace {
     hipEvent_t t0 = nullptr, t1 = nullptr;  // around the dominant kernel of the launch that used this slot
     bool timed = false;                     // t0/t1 hold an un-harvested measurement
     bool busy = false;
+    bool recorded = false;                  // `done` has been recorded for the current user (until then the event still
+                                            // shows the PREVIOUS launch as complete: the slot must not be reclaimed)
 };
 
 cls::PlaceParams resolve(const cls_params* p) {
@@ -218,12 +220,13 @@ static void harvest(cls_db* db, Workspace& w) {
 }
 
 // Take (or add) a scratch workspace whose previous user has finished.
-static int acquire_ws(cls_db* db, uint64_t words, size_t* slot) {
+// `*use` = a copy of the slot taken under the lock: the vector may grow (and move) while the caller launches.
+static int acquire_ws(cls_db* db, uint64_t words, size_t* slot, Workspace* use) {
     std::lock_guard<std::mutex> g(db->ws_mu);
     for (size_t i = 0; i < db->ws.size(); ++i) {
         Workspace& w = db->ws[i];
-        if (w.busy && hipEventQuery(w.done) == hipSuccess) { w.busy = false; harvest(db, w); }
-        if (!w.busy && w.words >= words) { w.busy = true; *slot = i; return CLS_OK; }
+        if (w.busy && w.recorded && hipEventQuery(w.done) == hipSuccess) { w.busy = false; harvest(db, w); }
+        if (!w.busy && w.words >= words) { w.busy = true; w.recorded = false; *slot = i; *use = w; return CLS_OK; }
     }
     Workspace w;
     if (hipMalloc((void**)&w.ptr, words * 4) != hipSuccess) return fail(CLS_E_NOMEM, "scratch workspace allocation failed");
@@ -234,8 +237,10 @@ static int acquire_ws(cls_db* db, uint64_t words, size_t* slot) {
     }
     w.words = words;
     w.busy = true;
+    w.recorded = false;
     db->ws.push_back(w);
     *slot = db->ws.size() - 1;
+    *use = w;
     return CLS_OK;
 }
 
@@ -258,15 +263,16 @@ static int place_device(cls_db* db, const void* d_bases, const void* d_offsets, 
     const cls::PlaceParams prm = resolve(params);
     const cls::PlacePlan plan = cls::plan_place(db->dev, n, (uint32_t)db->n_cu, d_stats != nullptr, long_cap, n_long);
     size_t slot = 0;
-    int rc = acquire_ws(db, (plan.ws_bytes + 3) / 4, &slot);
+    Workspace use;
+    int rc = acquire_ws(db, (plan.ws_bytes + 3) / 4, &slot, &use);
     if (rc != CLS_OK) return rc;
     hipError_t e = cls::launch_place(db->dev, prm, plan, (const uint8_t*)d_bases, (const uint64_t*)d_offsets, n,
-                                     (cls_placement*)d_out, (cls_query_stats*)d_stats, db->ws[slot].ptr, stream,
-                                     db->ws[slot].t0, db->ws[slot].t1);
+                                     (cls_placement*)d_out, (cls_query_stats*)d_stats, use.ptr, stream, use.t0, use.t1);
     {
         std::lock_guard<std::mutex> g(db->ws_mu);
         db->ws[slot].timed = (e == hipSuccess);
         if (hipEventRecord(db->ws[slot].done, stream) != hipSuccess) { db->ws[slot].busy = false; db->ws[slot].timed = false; }
+        db->ws[slot].recorded = true;
     }
     if (e != hipSuccess) return fail(CLS_E_HIP, std::string("kernel launch failed: ") + hipGetErrorString(e));
     return CLS_OK;
@@ -291,6 +297,7 @@ extern "C" int cls_db_kernel_time(cls_db* db, double* sum_ms, uint64_t* launches
     if (!db) return fail(CLS_E_INVALID_ARG, "cls_db_kernel_time: null handle");
     std::lock_guard<std::mutex> g(db->ws_mu);
     for (auto& w : db->ws) {
+        if (w.busy && !w.recorded) continue;  // a launch in progress on another thread: its time is harvested later
         if (w.busy) { if (hipEventSynchronize(w.done) != hipSuccess) return fail(CLS_E_HIP, "hipEventSynchronize failed"); w.busy = false; }
         harvest(db, w);
     }

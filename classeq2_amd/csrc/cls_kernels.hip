@@ -1495,8 +1495,9 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void order_key_kernel(DbDev d
         const uint64_t b0 = offsets[r], L64 = offsets[r + 1] - b0;
         uint64_t key = ~0ull;
         if (L64 >= db.k && 2 * (L64 - db.k + 1) <= (uint64_t)key_cap) {
-            // reads of the next class (up to key_cap k-mers) are keyed by their first 32*SLOTS windows: the same
-            // sorted list then orders both wave-per-read kernels
+            // every read is keyed by its first 32*SLOTS windows (64 by default: a third of the lookups of a 150 bp read
+            // cost 1.3 ms less than the slightly coarser order costs the placement kernel); reads of the next class
+            // (up to key_cap k-mers) too: the same sorted list then orders both wave-per-read kernels
             const uint32_t L = (uint32_t)std::min<uint64_t>(L64, 32 * SLOTS + db.k - 1), nf = L - db.k + 1, nk = 2 * nf;
             constexpr int LS = FWD ? (SLOTS + 1) / 2 : SLOTS;  // one lookup per window needs half the slots
             uint4 ent[LS];
@@ -2183,14 +2184,23 @@ hipError_t launch_place(const DbDev& db, const PlaceParams& prm, const PlacePlan
         static const uint32_t sample_shift = [] { const char* v = getenv("CLS_ORDER_SAMPLE_SHIFT"); return v ? (uint32_t)atoi(v) : 32u; }();
         static const uint32_t block_shift = [] { const char* v = getenv("CLS_ORDER_BLOCK_SHIFT"); return v ? (uint32_t)atoi(v) : 2u; }();
         const size_t smem_k = (size_t)WAVES_PER_BLOCK * (ac + (db.direct ? 4u * (((ac >> 4) + 2 + 3) & ~3u) : 0u) + 16u);
-#define CLS_LAUNCH_KEY(A32, FW, HS)                                                                                                       \
-    hipLaunchKernelGGL((order_key_kernel<CLS_SLOTS[0], A32, FW, HS>), dim3(plan.grid_key), dim3(64 * WAVES_PER_BLOCK), smem_k, stream, db, \
+        // windows of a read that make its key (CLS_ORDER_WINDOWS; 64 = one lookup slot per lane, 160 = all of a 150 bp read)
+        static const uint32_t key_windows = [] { const char* v = getenv("CLS_ORDER_WINDOWS"); return v ? (uint32_t)atoi(v) : 64u; }();
+#define CLS_LAUNCH_KEY_S(SL, A32, FW, HS)                                                                                                 \
+    hipLaunchKernelGGL((order_key_kernel<SL, A32, FW, HS>), dim3(plan.grid_key), dim3(64 * WAVES_PER_BLOCK), smem_k, stream, db,          \
                        d_bases, d_offsets, n_reads, keys_in, idx_in, ac, tip_bits, spec_lg, block_shift, sample_shift, fwd_only,          \
                        (uint32_t)(64 * CLS_SLOTS[1]))
-        if (fast_mode(db) == 2) { if (fwd_only) CLS_LAUNCH_KEY(true, true, true); else CLS_LAUNCH_KEY(true, false, true); }
-        else if (db.addr32) { if (fwd_only) CLS_LAUNCH_KEY(true, true, false); else CLS_LAUNCH_KEY(true, false, false); }
-        else { if (fwd_only) CLS_LAUNCH_KEY(false, true, false); else CLS_LAUNCH_KEY(false, false, false); }
+#define CLS_LAUNCH_KEY(A32, HS)                                                                                                           \
+    do {                                                                                                                                  \
+        if (fwd_only && key_windows <= 64) CLS_LAUNCH_KEY_S(2, A32, true, HS);                                                            \
+        else if (fwd_only) CLS_LAUNCH_KEY_S(CLS_SLOTS[0], A32, true, HS);                                                                 \
+        else CLS_LAUNCH_KEY_S(CLS_SLOTS[0], A32, false, HS);                                                                              \
+    } while (0)
+        if (fast_mode(db) == 2) CLS_LAUNCH_KEY(true, true);
+        else if (db.addr32) CLS_LAUNCH_KEY(true, false);
+        else CLS_LAUNCH_KEY(false, false);
 #undef CLS_LAUNCH_KEY
+#undef CLS_LAUNCH_KEY_S
         e = sort_pairs(d_ws + plan.sort_off_words, plan.sort_bytes, keys_in, keys_out, idx_in, idx_out, n_reads, order_key_bits(db), stream);
         if (e != hipSuccess) return e;
         list0 = idx_out;

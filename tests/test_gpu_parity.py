@@ -227,25 +227,28 @@ def test_option_corner_values():
 
 
 def test_concurrent_host_calls_are_reentrant():
-    """cls_place_batch from several threads on one handle (own stream + scratch per call)."""
+    """cls_place_batch from several threads on one handle (own stream per call, scratch slots handed out under a lock):
+    batches of different sizes, so that slots are added and recycled while other calls are still launching."""
     import threading
     s = SynthDb(200, 500, 10, 4)
     bases, offsets, _ = s.reads(6000, 150)
     want = op.OraclePort(s.flat).place_batch(bases, offsets, threads=8)
-    results, errors = {}, []
+    sizes = [6000, 700, 4500, 90, 5200, 2000, 6000, 300]
+    errors = []
     with engine.PlacementDb(s.flat, device=0) as db:
         def work(i):
             try:
-                for _ in range(3):
-                    results[i] = db.place_batch(bases, offsets)
+                for it in range(6):
+                    n = sizes[(i + it) % len(sizes)]
+                    got = db.place_batch(bases[: 150 * n], offsets[: n + 1])
+                    if len(records_equal(got, want[:n])) != 0:
+                        errors.append((i, it, n))
             except Exception as e:  # pragma: no cover
                 errors.append(e)
-        th = [threading.Thread(target=work, args=(i,)) for i in range(4)]
+        th = [threading.Thread(target=work, args=(i,)) for i in range(8)]
         [t.start() for t in th]
         [t.join() for t in th]
     assert not errors, errors
-    for i in range(4):
-        assert len(records_equal(results[i], want)) == 0
 
 
 def test_index_format_selection():
