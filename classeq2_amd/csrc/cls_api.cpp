@@ -41,6 +41,16 @@ struct Workspace {
                                             // shows the PREVIOUS launch as complete: the slot must not be reclaimed)
 };
 
+// Stream + device staging buffers of one host-buffer call, recycled across calls (a hipMalloc / hipFree / stream
+// create per call cost milliseconds -- and hipFree synchronises the device, stalling every other caller).
+struct CallSlot {
+    hipStream_t stream = nullptr;
+    void *d_bases = nullptr, *d_off = nullptr, *d_out = nullptr, *d_stats = nullptr;
+    uint64_t cap_bytes = 0;
+    uint32_t cap_reads = 0, cap_stats = 0;
+    bool busy = false;
+};
+
 cls::PlaceParams resolve(const cls_params* p) {
     // place_sequence.rs:64-75
     cls::PlaceParams r;
@@ -73,6 +83,7 @@ struct cls_db {
     double kernel_ms_sum = 0.0;
     uint64_t kernel_launches = 0;
     std::vector<Workspace> ws;  // per-call scratch (class lists, child counters), recycled once their launch has finished
+    std::vector<CallSlot> calls;  // host-buffer calls: stream + staging buffers (ws_mu)
 };
 
 extern "C" const char* cls_last_error(void) { return g_err.c_str(); }
@@ -96,6 +107,10 @@ extern "C" void cls_db_destroy(cls_db* db) {
         if (w.t0) (void)hipEventDestroy(w.t0);
         if (w.t1) (void)hipEventDestroy(w.t1);
         if (w.ptr) (void)hipFree(w.ptr);
+    }
+    for (auto& c : db->calls) {
+        if (c.stream) { (void)hipStreamSynchronize(c.stream); (void)hipStreamDestroy(c.stream); }
+        for (void* p : {c.d_bases, c.d_off, c.d_out, c.d_stats}) if (p) (void)hipFree(p);
     }
     if (db->d_nodes) (void)hipFree(db->d_nodes);
     if (db->d_table) (void)hipFree(db->d_table);
@@ -317,47 +332,60 @@ static int place_host(cls_db* db, const char* bases, const uint64_t* offsets, ui
     int prev = 0;
     CLS_HIP(hipGetDevice(&prev));
     CLS_HIP(hipSetDevice(db->device));
-    hipStream_t stream = nullptr;
-    void *d_bases = nullptr, *d_off = nullptr, *d_out = nullptr, *d_stats = nullptr;
+    // a call slot of the handle's pool: its stream and (grow-only) staging buffers
+    size_t ci = 0;
+    CallSlot cs;
+    {
+        std::lock_guard<std::mutex> g(db->ws_mu);
+        for (ci = 0; ci < db->calls.size() && db->calls[ci].busy; ++ci) {}
+        if (ci == db->calls.size()) db->calls.emplace_back();
+        db->calls[ci].busy = true;
+        cs = db->calls[ci];
+    }
     int rc = CLS_OK;
-    auto cleanup = [&]() {
-        if (d_bases) (void)hipFree(d_bases);
-        if (d_off) (void)hipFree(d_off);
-        if (d_out) (void)hipFree(d_out);
-        if (d_stats) (void)hipFree(d_stats);
-        if (stream) (void)hipStreamDestroy(stream);
+    auto cleanup = [&]() {  // hand the slot (with whatever it has grown to) back
+        std::lock_guard<std::mutex> g(db->ws_mu);
+        cs.busy = false;
+        db->calls[ci] = cs;
         (void)hipSetDevice(prev);
     };
+    hipStream_t& stream = cs.stream;
+    void *&d_bases = cs.d_bases, *&d_off = cs.d_off, *&d_out = cs.d_out, *&d_stats = cs.d_stats;
 #define CLS_TRY(expr)                                                                                     \
     do {                                                                                                  \
         hipError_t e_ = (expr);                                                                           \
-        if (e_ != hipSuccess) { cleanup(); return fail(e_ == hipErrorOutOfMemory ? CLS_E_NOMEM : CLS_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); } \
+        if (e_ != hipSuccess) { if (stream) (void)hipStreamSynchronize(stream); cleanup(); return fail(e_ == hipErrorOutOfMemory ? CLS_E_NOMEM : CLS_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); } \
     } while (0)
     try {
-        CLS_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+        if (!stream) CLS_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
         // bounded device footprint: chunks of <= 4M reads and <= 1 GiB of bases
         const uint32_t max_reads = 4u << 20;
         const uint64_t max_bytes = 1ull << 30;
         std::vector<uint64_t> rel;
-        uint64_t cap_bytes = 0;
-        uint32_t cap_reads = 0;
         for (uint32_t first = 0; first < n;) {
             uint32_t cnt = 0;
             while (first + cnt < n && cnt < max_reads && (cnt == 0 || offsets[first + cnt + 1] - offsets[first] <= max_bytes)) ++cnt;
             const uint64_t nbytes = offsets[first + cnt] - offsets[first];
-            if (nbytes > cap_bytes || !d_bases) {
-                if (d_bases) { (void)hipFree(d_bases); d_bases = nullptr; }
-                CLS_TRY(hipMalloc(&d_bases, nbytes ? nbytes : 16));
-                cap_bytes = nbytes;
+            if (nbytes > cs.cap_bytes || !d_bases) {
+                if (d_bases) { (void)hipFree(d_bases); d_bases = nullptr; cs.cap_bytes = 0; }
+                const uint64_t want = std::max<uint64_t>(nbytes + nbytes / 4, 1 << 16);  // (some slack: jobs of similar size reuse it)
+                CLS_TRY(hipMalloc(&d_bases, want));
+                cs.cap_bytes = want;
             }
-            if (cnt > cap_reads) {
+            if (cnt > cs.cap_reads) {
                 if (d_off) { (void)hipFree(d_off); d_off = nullptr; }
                 if (d_out) { (void)hipFree(d_out); d_out = nullptr; }
                 if (d_stats) { (void)hipFree(d_stats); d_stats = nullptr; }
-                CLS_TRY(hipMalloc(&d_off, ((size_t)cnt + 1) * 8));
-                CLS_TRY(hipMalloc(&d_out, (size_t)cnt * sizeof(cls_placement)));
-                if (stats) CLS_TRY(hipMalloc(&d_stats, (size_t)cnt * sizeof(cls_query_stats)));
-                cap_reads = cnt;
+                cs.cap_reads = cs.cap_stats = 0;
+                const uint32_t want = (uint32_t)std::min<uint64_t>(max_reads, std::max<uint64_t>((uint64_t)cnt + cnt / 4, 1024));
+                CLS_TRY(hipMalloc(&d_off, ((size_t)want + 1) * 8));
+                CLS_TRY(hipMalloc(&d_out, (size_t)want * sizeof(cls_placement)));
+                cs.cap_reads = want;
+            }
+            if (stats && cs.cap_stats < cs.cap_reads) {
+                if (d_stats) { (void)hipFree(d_stats); d_stats = nullptr; }
+                CLS_TRY(hipMalloc(&d_stats, (size_t)cs.cap_reads * sizeof(cls_query_stats)));
+                cs.cap_stats = cs.cap_reads;
             }
             rel.resize((size_t)cnt + 1);
             for (uint32_t i = 0; i <= cnt; ++i) rel[i] = offsets[first + i] - offsets[first];
@@ -371,8 +399,8 @@ static int place_host(cls_db* db, const char* bases, const uint64_t* offsets, ui
             }
             if (nbytes) CLS_TRY(hipMemcpyAsync(d_bases, bases + offsets[first], nbytes, hipMemcpyHostToDevice, stream));
             CLS_TRY(hipMemcpyAsync(d_off, rel.data(), ((size_t)cnt + 1) * 8, hipMemcpyHostToDevice, stream));
-            rc = place_device(db, d_bases, d_off, cnt, params, d_out, d_stats, stream, (uint32_t)(2 * longest), n_long);
-            if (rc != CLS_OK) { cleanup(); return rc; }
+            rc = place_device(db, d_bases, d_off, cnt, params, d_out, stats ? d_stats : nullptr, stream, (uint32_t)(2 * longest), n_long);
+            if (rc != CLS_OK) { (void)hipStreamSynchronize(stream); cleanup(); return rc; }
             CLS_TRY(hipMemcpyAsync(out + first, d_out, (size_t)cnt * sizeof(cls_placement), hipMemcpyDeviceToHost, stream));
             if (stats) CLS_TRY(hipMemcpyAsync(stats + first, d_stats, (size_t)cnt * sizeof(cls_query_stats), hipMemcpyDeviceToHost, stream));
             CLS_TRY(hipStreamSynchronize(stream));

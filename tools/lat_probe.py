@@ -1,0 +1,16 @@
+"""Experiment: latency of small host-buffer calls (what a service job sees)."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from classeq2_amd import engine
+from classeq2_amd.synth import SynthDb
+s = SynthDb(1000, 1500, 12, 4)
+db = engine.PlacementDb(s.flat, device=0)
+for n in (1, 100, 1000, 10000, 100000):
+    bases, offsets, _ = s.reads(n, 150)
+    for _ in range(3): db.place_batch(bases, offsets)
+    t = time.perf_counter()
+    reps = 20
+    for _ in range(reps): db.place_batch(bases, offsets)
+    dt = (time.perf_counter() - t) / reps
+    print(f"n={n:7d}: {dt*1e3:8.3f} ms per call -> {n/dt/1e6:8.3f} M reads/s")
