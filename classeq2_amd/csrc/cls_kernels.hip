@@ -1551,6 +1551,108 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void order_key_kernel(DbDev d
     }
 }
 
+// The same key from the read's first 64 windows, written for throughput: a HALF wavefront per read (two reads in
+// flight per wave: the kernel is bound by the latency of its two dependent reads, bases then table), two windows per
+// lane, canonical lookups through the direct table.  Ballots are taken wave-wide and split by half.
+template <bool ADDR32>
+__global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void order_key_half_kernel(DbDev db, const uint8_t* __restrict__ bases,
+                                                                            const uint64_t* __restrict__ offsets, uint32_t n_reads,
+                                                                            uint64_t* __restrict__ keys, uint32_t* __restrict__ idx,
+                                                                            uint32_t tip_bits, uint32_t spec_lg, uint32_t block_shift,
+                                                                            uint32_t key_cap) {
+    constexpr uint32_t MAXL = 64 + DIRECT_MAX_K - 1 + 1;  // first 64 windows
+    constexpr uint32_t WORDS = (MAXL + 15) / 16 + 2;
+    __shared__ __align__(16) uint8_t s_ascii[WAVES_PER_BLOCK * 2][(MAXL + 19) & ~3u];
+    __shared__ uint32_t s_packed[WAVES_PER_BLOCK * 2][WORDS];
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63, half = lane >> 5, hl = lane & 31;
+    uint8_t* ascii = s_ascii[wave * 2 + half];
+    uint32_t* packed = s_packed[wave * 2 + half];
+    const uint32_t k = db.k;
+    const uint32_t kmask = (1u << (2 * k)) - 1u;  // k <= 15
+    const uint32_t* __restrict__ direct = db.direct;
+    const uint32_t pair0 = (blockIdx.x * WAVES_PER_BLOCK + wave) * 2, stride = gridDim.x * WAVES_PER_BLOCK * 2;
+    auto half_of = [&](uint64_t m) { return (uint32_t)(m >> (32 * half)); };  // this half's 32 bits of a wave-wide ballot
+    for (uint32_t r0 = pair0; r0 < n_reads; r0 += stride) {  // (uniform trip count per wave: r0 is the pair's first read)
+        const uint32_t r = r0 + half;
+        const bool have = r < n_reads;
+        const uint64_t b0 = have ? offsets[r] : 0, L64 = have ? offsets[r + 1] - b0 : 0;
+        const bool keyed = have && L64 >= k && 2 * (L64 - k + 1) <= (uint64_t)key_cap;
+        const uint32_t L = keyed ? (uint32_t)std::min<uint64_t>(L64, 64 + k - 1) : 0, nf = keyed ? L - k + 1 : 0;
+        bool bad = false;
+        for (uint32_t i = hl; i < L; i += 32) {
+            uint8_t c = bases[b0 + i];
+            if (c >= 'a' && c <= 'z') c -= 32;
+            bad |= !(c == 'A' || c == 'C' || c == 'G' || c == 'T');
+            ascii[i] = c;
+        }
+        const bool ok = keyed && half_of(__ballot(bad)) == 0;
+        wave_sync();
+        for (uint32_t w = hl; w < (L + 15) / 16 + 1; w += 32) {
+            uint32_t acc = 0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {  // 4 ascii bytes -> 8 bits: (c >> 1) & 3 = A0 C1 T2 G3
+                uint32_t t = *reinterpret_cast<const uint32_t*>(ascii + 16 * w + 4 * q);  // reads past L stay inside the buffer
+                t = (t >> 1) & 0x03030303u;
+                t = (t | (t >> 6) | (t >> 12) | (t >> 18)) & 0xFFu;
+                acc |= t << (8 * q);
+            }
+            if (w < WORDS) packed[w] = acc;
+        }
+        wave_sync();
+        uint32_t off[2], meta[2];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const uint32_t p = hl + 32 * s;
+            const bool valid = ok && p < nf;
+            const uint32_t w = valid ? p >> 4 : 0, sh = valid ? (2 * p) & 31 : 0;
+            const uint32_t d0 = packed[w], d1 = packed[w + 1];
+            uint32_t code = (uint32_t)((((uint64_t)d1 << 32) | d0) >> sh) & kmask;
+            uint32_t rcc = __builtin_bitreverse32(code ^ (0xAAAAAAAAu & kmask));
+            rcc = ((rcc >> 1) & 0x55555555u) | ((rcc & 0x55555555u) << 1);
+            rcc >>= (32 - 2 * k);
+            code = rcc < code ? rcc : code;  // the same entry whichever strand was read
+            const uint4 e = ldx<uint4, ADDR32>(direct, valid ? code : 0u);
+            off[s] = valid ? e.x : 0u;
+            meta[s] = valid ? e.z : 0xFFFFFFFFu;
+        }
+        // candidates: k-mers present in the index that are specific to a small clade; widen the bound until a few qualify
+        uint32_t cand = 0, n_cand = 0, lg_max = spec_lg;
+        for (int tier = 0; tier < 4; ++tier, lg_max = tier == 3 ? 31u : lg_max + 3u) {
+            const bool need = n_cand < 4;  // (per half; the other half may already be done)
+            uint32_t c_new = 0, n_new = 0;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const bool c = off[s] != 0 && (meta[s] >> DIRECT_TIP_BITS) <= lg_max;
+                c_new |= (c ? 1u : 0u) << s;
+                n_new += (uint32_t)__popc(half_of(__ballot(c)));
+            }
+            if (need) { cand = c_new; n_cand = n_new; }
+            if (__ballot(n_cand < 4) == 0) break;
+        }
+        // median first tip of the candidates: radix select, one bit per round
+        uint32_t rank = n_cand >> 1, prefix = 0;
+        for (int bit = (int)tip_bits - 1; bit >= 0; --bit) {
+            uint32_t c0 = 0;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const uint32_t t = meta[s] & DIRECT_TIP_MASK;
+                const bool z = ((cand >> s) & 1u) && ((t ^ prefix) >> (bit + 1)) == 0 && !((t >> bit) & 1u);
+                c0 += (uint32_t)__popc(half_of(__ballot(z)));
+            }
+            if (rank >= c0) { rank -= c0; prefix |= 1u << bit; }
+        }
+        uint32_t mh = 0xFFFFFFFFu;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) if ((cand >> s) & 1u) mh = off[s] < mh ? off[s] : mh;
+        for (int o = 16; o > 0; o >>= 1) { const uint32_t other = __shfl_xor(mh, o); mh = other < mh ? other : mh; }
+        if (have && hl == 0) {
+            keys[r] = (ok && n_cand) ? (((uint64_t)(prefix >> block_shift) << db.hdr_bits) | mh) : ~0ull;
+            idx[r] = r;
+        }
+        wave_sync();
+    }
+}
+
 // ---- long reads: one WORKGROUP per read, per-k-mer state in global scratch ---------------------------
 // Reads with more k-mers than the register-resident kernels hold (marker genes are a few kb, BASELINE
 // config 5 has 10 kb reads).  Same algorithm, written one k-mer per thread and trip: the read is not
@@ -2196,7 +2298,17 @@ hipError_t launch_place(const DbDev& db, const PlaceParams& prm, const PlacePlan
         else if (fwd_only) CLS_LAUNCH_KEY_S(CLS_SLOTS[0], A32, true, HS);                                                                 \
         else CLS_LAUNCH_KEY_S(CLS_SLOTS[0], A32, false, HS);                                                                              \
     } while (0)
-        if (fast_mode(db) == 2) CLS_LAUNCH_KEY(true, true);
+        if (fast_mode(db) != 2 && fwd_only && key_windows == 64 && sample_shift >= 32) {
+            // (the default: two reads per wavefront)
+            const uint32_t grid_half = std::max<uint32_t>(1, std::min<uint32_t>((n_reads + 2 * WAVES_PER_BLOCK - 1) / (2 * WAVES_PER_BLOCK), plan.grid_key));
+            if (db.addr32)
+                hipLaunchKernelGGL((order_key_half_kernel<true>), dim3(grid_half), dim3(64 * WAVES_PER_BLOCK), 0, stream, db, d_bases, d_offsets,
+                                   n_reads, keys_in, idx_in, tip_bits, spec_lg, block_shift, (uint32_t)(64 * CLS_SLOTS[1]));
+            else
+                hipLaunchKernelGGL((order_key_half_kernel<false>), dim3(grid_half), dim3(64 * WAVES_PER_BLOCK), 0, stream, db, d_bases, d_offsets,
+                                   n_reads, keys_in, idx_in, tip_bits, spec_lg, block_shift, (uint32_t)(64 * CLS_SLOTS[1]));
+        }
+        else if (fast_mode(db) == 2) CLS_LAUNCH_KEY(true, true);
         else if (db.addr32) CLS_LAUNCH_KEY(true, false);
         else CLS_LAUNCH_KEY(false, false);
 #undef CLS_LAUNCH_KEY
