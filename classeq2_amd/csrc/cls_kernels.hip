@@ -1,16 +1,21 @@
 // HIP kernels of the placement path (gfx950 / CDNA4, wave64).
 //
-// One WAVEFRONT places one read (reads of up to 64*SLOTS k-mers):
-//   A. k-mer extraction (forward + reverse complement, kmers_map.rs:375-398),
-//      MurmurHash3 keying (kmers_map.rs:157-159), probe of the HBM-resident
-//      k-mer table, minimizer-bucket filter and distinct-hash de-duplication
-//      (kmers_map.rs:273-311) -- one k-mer per (lane, slot);
+// The algorithm per read (place_sequence.rs:42-601):
+//   A. k-mer extraction (forward + reverse complement, kmers_map.rs:375-398), keying (MurmurHash3,
+//      kmers_map.rs:157-159, or the 2-bit code through the direct table), lookup in the HBM-resident index,
+//      minimizer-bucket filter and distinct-hash de-duplication (kmers_map.rs:273-311);
 //   B. thresholds (place_sequence.rs:98-139, :156-166, :231-254);
-//   C. top-down clade descent (place_sequence.rs:279-601): per level every
-//      lane classifies its k-mers against the children's pre-order intervals,
-//      __ballot/__popcll give |K_c|, |only_c|, |U| -> the one-vs-rest test.
-// Integer set membership only: no MFMA.  See DESIGN.md for the data layout and
-// the roofline accounting.
+//   C. top-down clade descent (place_sequence.rs:279-601): per level |K_c|, |only_c|, |U| over the children's
+//      pre-order intervals -> the one-vs-rest test -> narrow to the chosen child.
+// Map of this file:
+//   match_phase / place_read / place_read_split   generic wave- or workgroup-per-read path, one k-mer per (lane, slot),
+//                                                  any k, any index (FMT_LIST and FMT_SPLIT), polytomies by a wave-wide walk
+//   fast_front / hash_front / place_read_fast      FMT_SPLIT fast path: direct-table or MurmurHash3 front, k-mers grouped
+//                                                  by tip set, descent on {set, weight} groups, per-group polytomy walk
+//   order_key_kernel / order_key_half_kernel        locality keys of the reads (sorted by cls_sort.hip)
+//   place_long_kernel                              reads beyond 8192 k-mers: state in the workspace
+//   classify_kernel, plan_place, launch_place      read-length classes, grids / scratch layout, launches
+// Integer set membership only: no MFMA.  See DESIGN.md for the data layout and the roofline accounting.
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
 
