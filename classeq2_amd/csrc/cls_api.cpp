@@ -332,80 +332,101 @@ static int place_host(cls_db* db, const char* bases, const uint64_t* offsets, ui
     int prev = 0;
     CLS_HIP(hipGetDevice(&prev));
     CLS_HIP(hipSetDevice(db->device));
-    // a call slot of the handle's pool: its stream and (grow-only) staging buffers
-    size_t ci = 0;
-    CallSlot cs;
+    // Large batches go through in chunks on TWO call slots (stream + grow-only staging buffers from the handle's pool):
+    // the copy-in of chunk i+1 and the copy-out of chunk i-1 overlap the kernels of chunk i.
+    const uint32_t chunk_reads = 256u << 10;       // reads per chunk (each chunk is still ordered as a whole: >= 4096 reads)
+    const uint64_t chunk_bytes = 256ull << 20;     // bases per chunk
+    const bool two = n > chunk_reads || offsets[n] - offsets[0] > chunk_bytes;
+    size_t ci[2] = {0, 0};
+    CallSlot cs[2];
+    const int n_slots = two ? 2 : 1;
     {
         std::lock_guard<std::mutex> g(db->ws_mu);
-        for (ci = 0; ci < db->calls.size() && db->calls[ci].busy; ++ci) {}
-        if (ci == db->calls.size()) db->calls.emplace_back();
-        db->calls[ci].busy = true;
-        cs = db->calls[ci];
+        for (int k = 0; k < n_slots; ++k) {
+            size_t i = 0;
+            while (i < db->calls.size() && db->calls[i].busy) ++i;
+            if (i == db->calls.size()) db->calls.emplace_back();
+            db->calls[i].busy = true;
+            ci[k] = i;
+            cs[k] = db->calls[i];
+        }
     }
-    int rc = CLS_OK;
-    auto cleanup = [&]() {  // hand the slot (with whatever it has grown to) back
+    auto cleanup = [&]() {  // drain, then hand the slots (with whatever they have grown to) back
+        for (int k = 0; k < n_slots; ++k) if (cs[k].stream) (void)hipStreamSynchronize(cs[k].stream);
         std::lock_guard<std::mutex> g(db->ws_mu);
-        cs.busy = false;
-        db->calls[ci] = cs;
+        for (int k = 0; k < n_slots; ++k) { cs[k].busy = false; db->calls[ci[k]] = cs[k]; }
         (void)hipSetDevice(prev);
     };
-    hipStream_t& stream = cs.stream;
-    void *&d_bases = cs.d_bases, *&d_off = cs.d_off, *&d_out = cs.d_out, *&d_stats = cs.d_stats;
 #define CLS_TRY(expr)                                                                                     \
     do {                                                                                                  \
         hipError_t e_ = (expr);                                                                           \
-        if (e_ != hipSuccess) { if (stream) (void)hipStreamSynchronize(stream); cleanup(); return fail(e_ == hipErrorOutOfMemory ? CLS_E_NOMEM : CLS_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); } \
+        if (e_ != hipSuccess) { cleanup(); return fail(e_ == hipErrorOutOfMemory ? CLS_E_NOMEM : CLS_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); } \
     } while (0)
     try {
-        if (!stream) CLS_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
-        // bounded device footprint: chunks of <= 4M reads and <= 1 GiB of bases
-        const uint32_t max_reads = 4u << 20;
-        const uint64_t max_bytes = 1ull << 30;
-        std::vector<uint64_t> rel;
-        for (uint32_t first = 0; first < n;) {
+        std::vector<uint64_t> rel[2];
+        struct Pending { bool on = false; uint32_t first = 0, cnt = 0; } pend[2];
+        auto copy_out = [&](int k) -> hipError_t {  // records (and counters) of the chunk slot k last ran
+            if (!pend[k].on) return hipSuccess;
+            pend[k].on = false;
+            hipError_t e = hipMemcpyAsync(out + pend[k].first, cs[k].d_out, (size_t)pend[k].cnt * sizeof(cls_placement), hipMemcpyDeviceToHost, cs[k].stream);
+            if (e == hipSuccess && stats)
+                e = hipMemcpyAsync(stats + pend[k].first, cs[k].d_stats, (size_t)pend[k].cnt * sizeof(cls_query_stats), hipMemcpyDeviceToHost, cs[k].stream);
+            return e;
+        };
+        int turn = 0;
+        for (uint32_t first = 0; first < n; turn ^= (n_slots - 1)) {
+            CallSlot& c = cs[turn];
             uint32_t cnt = 0;
-            while (first + cnt < n && cnt < max_reads && (cnt == 0 || offsets[first + cnt + 1] - offsets[first] <= max_bytes)) ++cnt;
+            while (first + cnt < n && cnt < chunk_reads && (cnt == 0 || offsets[first + cnt + 1] - offsets[first] <= chunk_bytes)) ++cnt;
             const uint64_t nbytes = offsets[first + cnt] - offsets[first];
-            if (nbytes > cs.cap_bytes || !d_bases) {
-                if (d_bases) { (void)hipFree(d_bases); d_bases = nullptr; cs.cap_bytes = 0; }
+            CLS_TRY(copy_out(turn));  // the slot's previous chunk leaves before its buffers are reused (stream order)
+            if (!c.stream) CLS_TRY(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
+            if (nbytes > c.cap_bytes || !c.d_bases) {
+                CLS_TRY(hipStreamSynchronize(c.stream));
+                if (c.d_bases) { (void)hipFree(c.d_bases); c.d_bases = nullptr; c.cap_bytes = 0; }
                 const uint64_t want = std::max<uint64_t>(nbytes + nbytes / 4, 1 << 16);  // (some slack: jobs of similar size reuse it)
-                CLS_TRY(hipMalloc(&d_bases, want));
-                cs.cap_bytes = want;
+                CLS_TRY(hipMalloc(&c.d_bases, want));
+                c.cap_bytes = want;
             }
-            if (cnt > cs.cap_reads) {
-                if (d_off) { (void)hipFree(d_off); d_off = nullptr; }
-                if (d_out) { (void)hipFree(d_out); d_out = nullptr; }
-                if (d_stats) { (void)hipFree(d_stats); d_stats = nullptr; }
-                cs.cap_reads = cs.cap_stats = 0;
-                const uint32_t want = (uint32_t)std::min<uint64_t>(max_reads, std::max<uint64_t>((uint64_t)cnt + cnt / 4, 1024));
-                CLS_TRY(hipMalloc(&d_off, ((size_t)want + 1) * 8));
-                CLS_TRY(hipMalloc(&d_out, (size_t)want * sizeof(cls_placement)));
-                cs.cap_reads = want;
+            if (cnt > c.cap_reads) {
+                CLS_TRY(hipStreamSynchronize(c.stream));
+                for (void** pp : {&c.d_off, &c.d_out, &c.d_stats}) if (*pp) { (void)hipFree(*pp); *pp = nullptr; }
+                c.cap_reads = c.cap_stats = 0;
+                const uint32_t want = (uint32_t)std::max<uint64_t>((uint64_t)cnt + cnt / 4, 1024);
+                CLS_TRY(hipMalloc(&c.d_off, ((size_t)want + 1) * 8));
+                CLS_TRY(hipMalloc(&c.d_out, (size_t)want * sizeof(cls_placement)));
+                c.cap_reads = want;
             }
-            if (stats && cs.cap_stats < cs.cap_reads) {
-                if (d_stats) { (void)hipFree(d_stats); d_stats = nullptr; }
-                CLS_TRY(hipMalloc(&d_stats, (size_t)cs.cap_reads * sizeof(cls_query_stats)));
-                cs.cap_stats = cs.cap_reads;
+            if (stats && c.cap_stats < c.cap_reads) {
+                CLS_TRY(hipStreamSynchronize(c.stream));
+                if (c.d_stats) { (void)hipFree(c.d_stats); c.d_stats = nullptr; }
+                CLS_TRY(hipMalloc(&c.d_stats, (size_t)c.cap_reads * sizeof(cls_query_stats)));
+                c.cap_stats = c.cap_reads;
             }
-            rel.resize((size_t)cnt + 1);
-            for (uint32_t i = 0; i <= cnt; ++i) rel[i] = offsets[first + i] - offsets[first];
+            std::vector<uint64_t>& ro = rel[turn];
+            ro.resize((size_t)cnt + 1);
+            for (uint32_t i = 0; i <= cnt; ++i) ro[i] = offsets[first + i] - offsets[first];
             // reads beyond the register-resident kernels: provision exactly what this chunk needs
             uint64_t longest = 0;
             uint32_t n_long = 0;
             for (uint32_t i = 0; i < cnt; ++i) {
-                const uint64_t len = rel[i + 1] - rel[i];
+                const uint64_t len = ro[i + 1] - ro[i];
                 const uint64_t nk = len < db->dev.k ? 0 : 2 * (len - db->dev.k + 1);
                 if (nk > cls::MAX_READ_KMERS) { ++n_long; longest = std::max(longest, std::min(len, HARD_MAX_READ_LEN)); }
             }
-            if (nbytes) CLS_TRY(hipMemcpyAsync(d_bases, bases + offsets[first], nbytes, hipMemcpyHostToDevice, stream));
-            CLS_TRY(hipMemcpyAsync(d_off, rel.data(), ((size_t)cnt + 1) * 8, hipMemcpyHostToDevice, stream));
-            rc = place_device(db, d_bases, d_off, cnt, params, d_out, stats ? d_stats : nullptr, stream, (uint32_t)(2 * longest), n_long);
-            if (rc != CLS_OK) { (void)hipStreamSynchronize(stream); cleanup(); return rc; }
-            CLS_TRY(hipMemcpyAsync(out + first, d_out, (size_t)cnt * sizeof(cls_placement), hipMemcpyDeviceToHost, stream));
-            if (stats) CLS_TRY(hipMemcpyAsync(stats + first, d_stats, (size_t)cnt * sizeof(cls_query_stats), hipMemcpyDeviceToHost, stream));
-            CLS_TRY(hipStreamSynchronize(stream));
+            if (nbytes) CLS_TRY(hipMemcpyAsync(c.d_bases, bases + offsets[first], nbytes, hipMemcpyHostToDevice, c.stream));
+            CLS_TRY(hipMemcpyAsync(c.d_off, ro.data(), ((size_t)cnt + 1) * 8, hipMemcpyHostToDevice, c.stream));
+            const int rc = place_device(db, c.d_bases, c.d_off, cnt, params, c.d_out, stats ? c.d_stats : nullptr, c.stream, (uint32_t)(2 * longest), n_long);
+            if (rc != CLS_OK) { cleanup(); return rc; }
+            pend[turn].on = true;
+            pend[turn].first = first;
+            pend[turn].cnt = cnt;
             first += cnt;
+            // while this chunk computes, bring the other slot's finished records home
+            if (n_slots == 2) CLS_TRY(copy_out(turn ^ 1));
         }
+        for (int k = 0; k < n_slots; ++k) CLS_TRY(copy_out(k));
+        for (int k = 0; k < n_slots; ++k) CLS_TRY(hipStreamSynchronize(cs[k].stream));
     } catch (const std::bad_alloc&) {
         cleanup();
         return fail(CLS_E_NOMEM, "cls_place_batch: out of host memory");

@@ -251,6 +251,25 @@ def test_concurrent_host_calls_are_reentrant():
     assert not errors, errors
 
 
+def test_host_entry_pipelines_large_batches():
+    """More than 256k reads through cls_place_batch: chunks alternate between two call slots (copies overlap kernels);
+    same records as one device-resident call, and as the oracle on a sample."""
+    s = SynthDb(400, 1200, 12, 4)
+    n = 700_000
+    bases, offsets, _ = s.reads(n, 100)
+    with engine.PlacementDb(s.flat, device=0) as db:
+        host, hst = db.place_batch(bases, offsets, want_stats=True)
+        dev, dst = _device_place(db, bases, offsets)
+        host2 = db.place_batch(bases, offsets)
+    assert len(records_equal(host, dev)) == 0 and len(stats_equal(hst, dst)) == 0 and len(records_equal(host2, dev)) == 0
+    pick = np.random.default_rng(1).choice(n, 20000, replace=False)
+    pick.sort()
+    sb = bases.reshape(n, 100)[pick].reshape(-1)
+    so = np.arange(len(pick) + 1, dtype=np.uint64) * 100
+    want = op.OraclePort(s.flat).place_batch(sb, so, threads=16)
+    assert len(records_equal(host[pick], want)) == 0
+
+
 def test_index_format_selection():
     """Which device layout / kernels an index gets."""
     cases = [
