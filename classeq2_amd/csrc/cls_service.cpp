@@ -53,13 +53,14 @@ struct cls_service {
     std::string in_flight_model;  // the worker is using this model's handle right now
     bool in_flight = false;
     bool stopping = false;
+    bool paused = false;  // the worker leaves the queue alone (cls_service_pause)
     cls_service_stats stats{};
     std::thread worker;
 
     void run() {
         std::unique_lock<std::mutex> lk(mu);
         for (;;) {
-            cv_work.wait(lk, [&] { return stopping || !queue.empty(); });
+            cv_work.wait(lk, [&] { return stopping || (!paused && !queue.empty()); });
             if (queue.empty()) { if (stopping) return; continue; }
             // everything that waits for the same model with the same parameters as the oldest job: one device batch
             std::vector<std::shared_ptr<Job>> group;
@@ -139,6 +140,7 @@ extern "C" void cls_service_destroy(cls_service* s) {
     {
         std::lock_guard<std::mutex> g(s->mu);
         s->stopping = true;
+        s->paused = false;
     }
     s->cv_work.notify_all();
     if (s->worker.joinable()) s->worker.join();
@@ -208,6 +210,16 @@ extern "C" int cls_service_wait(cls_service* s, uint64_t ticket, cls_fasta* fa, 
     }
     *fa = j->fa;
     *records = j->records;
+    return CLS_OK;
+}
+
+extern "C" int cls_service_pause(cls_service* s, int paused) {
+    if (!s) return sv_fail(CLS_E_INVALID_ARG, "cls_service_pause: null handle");
+    {
+        std::lock_guard<std::mutex> g(s->mu);
+        s->paused = paused != 0;
+    }
+    s->cv_work.notify_all();
     return CLS_OK;
 }
 

@@ -32,7 +32,8 @@ HOST_EXPORTS = [
     "cls_host_free", "cls_place_sequences", "cls_host_last_error",
 ]
 SERVICE_EXPORTS = [
-    "cls_service_create", "cls_service_destroy", "cls_service_add_model", "cls_service_submit", "cls_service_wait", "cls_service_stats_get",
+    "cls_service_create", "cls_service_destroy", "cls_service_add_model", "cls_service_submit", "cls_service_wait", "cls_service_pause",
+    "cls_service_stats_get",
 ]
 FORMAT_YAML, FORMAT_JSONL = 0, 1
 DB_FORMAT_ZSTD, DB_FORMAT_YAML, DB_FORMAT_JSON = 0, 1, 2
@@ -125,6 +126,8 @@ def lib():
         L.cls_service_submit.restype = i32
         L.cls_service_wait.argtypes = [vp, C.c_uint64, C.POINTER(_abi.Fasta), C.POINTER(vp)]
         L.cls_service_wait.restype = i32
+        L.cls_service_pause.argtypes = [vp, i32]
+        L.cls_service_pause.restype = i32
         L.cls_service_stats_get.argtypes = [vp, C.POINTER(_abi.ServiceStats)]
         L.cls_service_stats_get.restype = i32
         _LIB = L
@@ -405,6 +408,9 @@ class Service:
         finally:
             lib().cls_fasta_free(C.byref(f))
             lib().cls_host_free(recs)
+
+    def pause(self, paused: bool = True) -> None:
+        _check(lib().cls_service_pause(self._h, 1 if paused else 0))
 
     def stats(self) -> dict:
         st = _abi.ServiceStats()

@@ -47,6 +47,10 @@ int cls_service_submit(cls_service* s, const char* model_id, const char* fasta_t
  * (CLS_OK, or the error of its batch). */
 int cls_service_wait(cls_service* s, uint64_t ticket, cls_fasta* fa, cls_placement** records);
 
+/* paused != 0: the worker leaves the queue alone (jobs keep being accepted) until it is resumed -- e.g. to let a burst
+ * of jobs accumulate into one batch per (model, parameters), or around maintenance of the registered models. */
+int cls_service_pause(cls_service* s, int paused);
+
 int cls_service_stats_get(cls_service* s, cls_service_stats* out);
 
 #ifdef __cplusplus

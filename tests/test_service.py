@@ -41,19 +41,31 @@ def test_jobs_share_batches_and_keep_their_results():
         for mid, s in models.items():
             svc.add_model(mid, engine.PlacementDb(s.flat, device=0))
 
-        def client(lo, hi):
+        def client(lo, hi, wait):
             tickets = [(i, svc.submit(jobs[i][0], jobs[i][1], engine.make_params(**jobs[i][2]) if jobs[i][2] else None)) for i in range(lo, hi)]
-            for i, t in tickets:
-                results[i] = svc.wait(t)
+            if wait:
+                for i, t in tickets:
+                    results[i] = svc.wait(t)
+            return tickets
 
-        th = [threading.Thread(target=client, args=(k * 30, (k + 1) * 30)) for k in range(8)]
+        # a burst while the worker is held: everything that waits with the same (model, parameters) becomes ONE batch
+        svc.pause(True)
+        held = client(0, 120, wait=False)
+        assert svc.stats()["jobs_done"] == 0
+        svc.pause(False)
+        for i, t in held:
+            results[i] = svc.wait(t)
+        st = svc.stats()
+        assert st["jobs_done"] == 120 and st["device_batches"] <= 6 and st["max_jobs_in_batch"] >= 120 // 6
+        # then concurrent clients against the running worker
+        th = [threading.Thread(target=client, args=(120 + k * 30, 120 + (k + 1) * 30, True)) for k in range(4)]
         [t.start() for t in th]
         [t.join() for t in th]
         st = svc.stats()
         with pytest.raises(engine.ClsError, match="unknown ticket"):
             svc.wait(1)
     assert st["jobs_submitted"] == st["jobs_done"] == 240 and st["models"] == 2
-    assert st["device_batches"] < 200 and st["max_jobs_in_batch"] > 1  # waiting jobs were merged
+    assert st["device_batches"] <= 6 + 120
     for i, (mid, text, kw, bases, offsets) in enumerate(jobs):
         headers, got, truncated = results[i]
         n = len(offsets) - 1
