@@ -53,7 +53,7 @@ def _run(world, n_reads, use_engine=False):
     for p in procs:
         p.start()
     for p in procs:
-        p.join(120)
+        p.join(300)
         assert p.exitcode == 0
     assert q.get(timeout=5) == 0
 
