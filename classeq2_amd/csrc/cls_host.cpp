@@ -634,44 +634,52 @@ extern "C" int cls_tree_desc(const cls_tree* t, cls_db_desc* d) {
     return CLS_OK;
 }
 
+// Records are independent: contiguous slices on the host's threads; the pieces are in input order.
+static void serialize_pieces(const cls_tree* t, const char* headers, const uint64_t* header_off, uint32_t n, const cls_placement* recs,
+                             int format, std::vector<std::string>& o, std::vector<std::string>& e) {
+    unsigned nt = std::max(1u, std::min(64u, std::thread::hardware_concurrency()));
+    if (n < 4096) nt = 1;
+    o.assign(nt, std::string());
+    e.assign(nt, std::string());
+    std::vector<std::string> errs(nt);
+    auto work = [&](unsigned w) {
+        try {
+            const uint32_t lo = (uint32_t)((uint64_t)n * w / nt), hi = (uint32_t)((uint64_t)n * (w + 1) / nt);
+            o[w].reserve((size_t)(hi - lo) * 360);
+            for (uint32_t i = lo; i < hi; ++i) {
+                const std::string header(headers + header_off[i], headers + header_off[i + 1]);
+                if (const char* et = error_text(recs[i].status)) { e[w] += et; continue; }  // mod.rs:160-169: appended without a newline
+                serialize_one(t, header, recs[i], format, o[w]);
+            }
+        } catch (const std::exception& ex) { errs[w] = ex.what(); if (errs[w].empty()) errs[w] = "error"; }
+    };
+    if (nt == 1) work(0);
+    else {
+        std::vector<std::thread> th;
+        for (unsigned w = 0; w < nt; ++w) th.emplace_back(work, w);
+        for (auto& x : th) x.join();
+    }
+    for (auto& m : errs) if (!m.empty()) throw std::runtime_error(m);
+}
+
 extern "C" int cls_serialize_results(const cls_tree* t, const char* headers, const uint64_t* header_off, uint32_t n,
                                      const cls_placement* recs, int format, char** out_text, size_t* out_len,
                                      char** err_text, size_t* err_len) {
     if (!t || !header_off || (!recs && n) || !out_text || !out_len) return fail(CLS_E_INVALID_ARG, "cls_serialize_results: null argument");
     try {
-        // records are independent: contiguous slices on the host's threads, concatenated in input order
-        unsigned nt = std::max(1u, std::min(64u, std::thread::hardware_concurrency()));
-        if (n < 4096) nt = 1;
-        std::vector<std::string> o(nt), e(nt);
-        std::vector<std::string> errs(nt);
-        auto work = [&](unsigned w) {
-            try {
-                const uint32_t lo = (uint32_t)((uint64_t)n * w / nt), hi = (uint32_t)((uint64_t)n * (w + 1) / nt);
-                o[w].reserve((size_t)(hi - lo) * 320);
-                for (uint32_t i = lo; i < hi; ++i) {
-                    const std::string header(headers + header_off[i], headers + header_off[i + 1]);
-                    if (const char* et = error_text(recs[i].status)) { e[w] += et; continue; }  // mod.rs:160-169: appended without a newline
-                    serialize_one(t, header, recs[i], format, o[w]);
-                }
-            } catch (const std::exception& ex) { errs[w] = ex.what(); if (errs[w].empty()) errs[w] = "error"; }
-        };
-        if (nt == 1) work(0);
-        else {
-            std::vector<std::thread> th;
-            for (unsigned w = 0; w < nt; ++w) th.emplace_back(work, w);
-            for (auto& x : th) x.join();
-        }
-        for (auto& m : errs) if (!m.empty()) return fail(CLS_E_INTERNAL, "cls_serialize_results: " + m);
+        std::vector<std::string> o, e;
+        serialize_pieces(t, headers, header_off, n, recs, format, o, e);
         size_t ol = 0, el = 0;
-        for (unsigned w = 0; w < nt; ++w) { ol += o[w].size(); el += e[w].size(); }
+        for (auto& x : o) ol += x.size();
+        for (auto& x : e) el += x.size();
         *out_text = (char*)malloc(ol + 1);
         if (!*out_text) return fail(CLS_E_NOMEM, "cls_serialize_results: out of memory");
-        { size_t p = 0; for (unsigned w = 0; w < nt; ++w) { memcpy(*out_text + p, o[w].data(), o[w].size()); p += o[w].size(); } }
+        { size_t p = 0; for (auto& x : o) { memcpy(*out_text + p, x.data(), x.size()); p += x.size(); } }
         (*out_text)[ol] = 0; *out_len = ol;
         if (err_text && err_len) {
             *err_text = (char*)malloc(el + 1);
             if (!*err_text) { free(*out_text); return fail(CLS_E_NOMEM, "cls_serialize_results: out of memory"); }
-            { size_t p = 0; for (unsigned w = 0; w < nt; ++w) { memcpy(*err_text + p, e[w].data(), e[w].size()); p += e[w].size(); } }
+            { size_t p = 0; for (auto& x : e) { memcpy(*err_text + p, x.data(), x.size()); p += x.size(); } }
             (*err_text)[el] = 0; *err_len = el;
         }
         return CLS_OK;
@@ -714,16 +722,12 @@ extern "C" int cls_place_sequences(cls_db* db, const cls_tree* t, const char* qu
         std::string().swap(text);
         const bool timing = getenv("CLS_TIMING") != nullptr;
         auto t2 = std::chrono::steady_clock::now();
-        char *ot = nullptr, *et = nullptr;
-        size_t ol = 0, el = 0;
-        rc = cls_serialize_results(t, fa.headers, fa.header_off, fa.n, recs, format, &ot, &ol, &et, &el);
+        std::vector<std::string> po, pe;  // the pieces go to the files as they are: no second copy of 300 MB of text
+        serialize_pieces(t, fa.headers, fa.header_off, fa.n, recs, format, po, pe);
         free(recs);
         auto t3 = std::chrono::steady_clock::now();
-        if (rc == CLS_OK) {
-            if (ol && fwrite(ot, 1, ol, fo) != ol) rc = fail(CLS_E_INTERNAL, "Error writing to file");
-            if (el && fwrite(et, 1, el, fe) != el) rc = fail(CLS_E_INTERNAL, "Error writing to file");
-        }
-        free(ot); free(et);
+        for (auto& x : po) if (!x.empty() && fwrite(x.data(), 1, x.size(), fo) != x.size()) rc = fail(CLS_E_INTERNAL, "Error writing to file");
+        for (auto& x : pe) if (!x.empty() && fwrite(x.data(), 1, x.size(), fe) != x.size()) rc = fail(CLS_E_INTERNAL, "Error writing to file");
         if (n_placed) *n_placed = fa.n;
         cls_fasta_free(&fa);
         fclose(fo); fclose(fe);
