@@ -1122,136 +1122,14 @@ __device__ __forceinline__ bool hash_front(const DbDev& db, const FastCtx& cx, c
     return true;
 }
 
-template <int SLOTS, int SET_BITS, bool STATS, bool ADDR32, int MODE, bool POLY>
-__device__ __forceinline__ void place_read_fast(const DbDev& db, const PlaceParams& prm, const FastCtx& cx,
-                                                const uint8_t* __restrict__ bases, uint64_t b0, uint64_t b1, uint32_t r,
-                                                cls_placement* __restrict__ out, cls_query_stats* __restrict__ stats,
-                                                uint32_t profile_stop_arg) {
-#ifdef CLS_PROFILE_HOOKS
-    const uint32_t profile_stop = profile_stop_arg;  // CLS_PROFILE_STOP=1|2: truncate after a phase (timing breakdowns)
-#else
-    constexpr uint32_t profile_stop = 0;  // (one less live scalar in a kernel that spills SGPRs)
-    (void)profile_stop_arg;
-#endif
+// The descent (C) on the read's tip-set groups, staged in cx.stage[0 .. n_sets).  PACK10: at most 1023 k-mers per read,
+// three 10-bit counters share a word.  (A two-kernel form -- front writes the groups, this runs as its own kernel at 39
+// VGPRs and 8 waves per SIMD -- was measured: 7.4 ms against 6.85 ms fused on C3; more reads in flight do not pay for
+// writing and re-reading 1.6 GB of groups.)
+template <bool PACK10, bool ADDR32, bool POLY>
+__device__ __forceinline__ void descend_groups(const DbDev& db, const PlaceParams& prm, const FastCtx& cx, uint32_t n_sets, snode_t P,
+                                               uint32_t r, cls_placement* __restrict__ out) {
     const uint32_t lane = threadIdx.x & 63;
-    const uint32_t k = db.k;
-    const uint64_t L64 = b1 - b0;
-    auto put_stats = [&](uint32_t nk_, uint32_t nm, uint32_t nr, uint64_t lp) {
-        if (STATS && stats && lane == 0) {
-            uint64_t* s = reinterpret_cast<uint64_t*>(stats + r);
-            s[0] = (uint64_t)nk_ | ((uint64_t)nm << 32);
-            s[1] = (uint64_t)nr;
-            s[2] = lp;
-        }
-    };
-    if (L64 < k) { put_stats(0, 0, 0, 0); write_record(out, r, CLS_ERR_TOO_FEW_KMERS, 0, 0, 0, 0); return; }
-    const uint32_t L = (uint32_t)L64, nf = L - k + 1, nk = 2 * nf;  // nk <= 64*SLOTS by classification
-    // ---- A1/A2. load + validate + 2-bit pack; per k-mer: code -> direct table ----------------------
-    // CANON (an index in which every k-mer and its reverse complement carry the same tip set, i.e. one built from
-    // both strands): the k-mers of window p on the two strands are reverse complements of each other, so ONE lookup
-    // of the smaller of the two answers for both; half the lookups, half the slots.
-    constexpr bool CANON = MODE == 1, HASHED = MODE == 2;  // MODE 0: direct table, both strands looked up
-    constexpr int LS = CANON ? (SLOTS + 1) / 2 : SLOTS;
-    uint4 ent[LS];
-    uint32_t kw[LS];
-    // the wide class sizes its LDS tables by the read (clearing 3 x 2048 entries cost more than placing a 250 bp read)
-    uint32_t tb = SET_BITS;
-    if constexpr (SET_BITS > 9) {
-        const uint32_t want = 2 * (CANON ? nf : nk);
-        tb = 9;
-        while ((1u << tb) < want && tb < (uint32_t)SET_BITS) ++tb;
-        tb = uniform(tb);
-    }
-    bool valid_read;
-    if constexpr (HASHED) valid_read = hash_front<LS, SET_BITS, ADDR32>(db, cx, bases, b0, L, nf, nk, ent, kw, tb);
-    else valid_read = fast_front<LS, SET_BITS, ADDR32>(db, cx, bases, b0, L, nf, CANON ? nf : nk, ent, kw, 32, CANON, tb);
-    if (!valid_read) {
-        put_stats(0, 0, 0, 0);
-        write_record(out, r, CLS_ERR_INVALID_BASE, 0, 0, 0, 0);
-        return;
-    }
-    const uint32_t* __restrict__ recs = db.postings;
-    // distinct hashes: the FIRST k-mer that reaches an entry keeps it (HashSet<u64> semantics)
-#pragma unroll
-    for (int s = 0; s < LS; ++s) {
-        if (ent[s].x != 0) {
-            const uint32_t key = ent[s].x;
-            uint32_t pos = (key * 2654435761u) >> (32 - tb);
-#pragma unroll 1
-            for (;;) {
-                const uint32_t old = atomicCAS(&cx.set[pos], SET_EMPTY, key);
-                if (old == SET_EMPTY) break;
-                if (old == key) { ent[s] = uint4{0u, 0u, 0xFFFFFFFFu, 0u}; kw[s] = 0; break; }
-                pos = (pos + 1) & ((1u << tb) - 1);
-            }
-        }
-    }
-    if (profile_stop == 1) { write_record(out, r, 0xFE, (int32_t)(ent[0].x + ent[LS - 1].x), 0, 0, 0); return; }  // profiling aid
-    // ---- A3. |M|, |M_root| (the descent state comes with the table entry: no header read) -----------------
-    uint32_t cnt = 0;  // |M| in bits 0..15, |M_root| in bits 16..31 (per lane, then summed)
-    uint64_t leafp = 0;
-#pragma unroll
-    for (int s = 0; s < LS; ++s) {
-        if (STATS) leafp += (uint64_t)kw[s] * ldx<uint4, ADDR32>(recs, ent[s].x + 1).x;  // record 1 (the dummy's second half) holds 0
-        cnt += (ent[s].x != 0 ? kw[s] : 0u) + ((ent[s].w >> 31) * kw[s] << 16);
-    }
-    cnt = wave_sum(cnt);
-    const uint32_t n_m = cnt & 0xFFFFu, n_root = cnt >> 16;
-    if (STATS) {
-        for (int o = 32; o > 0; o >>= 1) leafp += ((uint64_t)__shfl_xor((uint32_t)(leafp >> 32), o) << 32) | __shfl_xor((uint32_t)leafp, o);
-        put_stats(nk, n_m, n_root, leafp);
-    }
-    if (profile_stop == 2) { write_record(out, r, 0xFE, (int32_t)(ent[0].z + ent[LS - 1].w), 0, 0, 0); return; }
-    // ---- B. thresholds ------------------------------------------------------------------------------
-    if (n_m == 0) { write_record(out, r, CLS_UNCLASSIFIABLE_NO_MATCH, 0, 0, 0, 0); return; }
-    if (n_root == 0) { write_record(out, r, CLS_UNCLASSIFIABLE_NO_ROOT, 0, 0, 0, 0); return; }
-    // node records through the scalar unit: a DNode is 8 dwords {pre, size, first_child, n_nonleaf, id lo, id hi, split, flags}
-    snode_t P = load_node(db.nodes, 0);
-    if (!(P.s[7] & 1u)) { write_record(out, r, CLS_ERR_ROOT_NO_CHILDREN, 0, 0, 0, 0); return; }
-    {
-        const double expected = round((double)n_m * prm.min_match_coverage);
-        const uint64_t exp_usize = (expected != expected) ? 0ull : (uint64_t)expected;
-        if ((uint64_t)n_root < exp_usize) { write_record(out, r, CLS_UNCLASSIFIABLE_COVERAGE, (int32_t)n_root, 0, 0, 0); return; }
-    }
-    // ---- A4. group the k-mers by tip set ----------------------------------------------------------------
-    // k-mers with the same tip list (they share their split tree: same root split, or the same single tip)
-    // stay together all the way down, so the descent runs on {set, number of k-mers} pairs: a 150 bp read
-    // has a few dozen of them.  The first k-mer to claim a key owns the group; the groups are compacted into
-    // the staging area (64 per chunk; chunk 0 then lives in registers, the others stay in LDS).
-    uint32_t n_sets = 0;
-    {
-        uint32_t pos[LS];
-        uint32_t owner = 0;
-#pragma unroll
-        for (int s = 0; s < LS; ++s) {
-            const uint32_t lo_ = ent[s].z & DIRECT_TIP_MASK, hi_ = ent[s].w & 0x7FFFFFFFu;
-            pos[s] = 0;
-            if (lo_ <= hi_) {  // has tips below the root (absent / tip-less entries hold {MAX, 0})
-                const uint32_t key = ent[s].y ? ent[s].y : (0x80000000u | lo_);
-                uint32_t p = (key * 2654435761u) >> (32 - tb);
-#pragma unroll 1
-                for (;;) {
-                    const uint32_t old = atomicCAS(&cx.gkey[p], SET_EMPTY, key);
-                    if (old == SET_EMPTY) { owner |= 1u << s; break; }
-                    if (old == key) break;
-                    p = (p + 1) & ((1u << tb) - 1);
-                }
-                atomicAdd(&cx.gcnt[p], kw[s]);
-                pos[s] = p;
-            }
-        }
-        wave_sync();
-#pragma unroll
-        for (int s = 0; s < LS; ++s) pos[s] = ((owner >> s) & 1u) ? cx.gcnt[pos[s]] : 0u;  // now: the group's weight
-        wave_sync();  // the tables are dead from here on: the staging area lies over them
-#pragma unroll
-        for (int s = 0; s < LS; ++s) {
-            const uint64_t m = __ballot((owner >> s) & 1u);
-            if ((owner >> s) & 1u)
-                cx.stage[n_sets + popc64(m & ((1ull << lane) - 1))] = uint4{ent[s].z & DIRECT_TIP_MASK, ent[s].w & 0x7FFFFFFFu, ent[s].y, pos[s]};
-            n_sets += popc64(m);
-        }
-    }
     const uint32_t n_chunks = uniform((n_sets + 63) >> 6);  // wave-uniform; >= 1 here (some k-mer has the root and tips... or none: then 0)
     if (n_sets + lane < 64 * n_chunks) cx.stage[n_sets + lane] = uint4{0xFFFFFFFFu, 0u, 0u, 0u};  // pad the last chunk with inactive entries
     wave_sync();
@@ -1263,7 +1141,6 @@ __device__ __forceinline__ void place_read_fast(const DbDev& db, const PlacePara
     // ---- C. descent -----------------------------------------------------------------------------------
     const uint32_t* __restrict__ half = db.postings;  // record x = 8-byte halves 2x (left part), 2x+1 (right part)
     const bool rm = prm.remove_intersection != 0;
-    constexpr bool PACK10 = SLOTS * 64 < 1024;  // three 10-bit counters in one word
     int32_t iteration = 0;
     for (;;) {
         ++iteration;
@@ -1423,6 +1300,139 @@ __device__ __forceinline__ void place_read_fast(const DbDev& db, const PlacePara
             cx.stage[c * 64 + lane] = g;
         }
     }
+}
+
+template <int SLOTS, int SET_BITS, bool STATS, bool ADDR32, int MODE, bool POLY>
+__device__ __forceinline__ void place_read_fast(const DbDev& db, const PlaceParams& prm, const FastCtx& cx,
+                                                const uint8_t* __restrict__ bases, uint64_t b0, uint64_t b1, uint32_t r,
+                                                cls_placement* __restrict__ out, cls_query_stats* __restrict__ stats,
+                                                uint32_t profile_stop_arg) {
+#ifdef CLS_PROFILE_HOOKS
+    const uint32_t profile_stop = profile_stop_arg;  // CLS_PROFILE_STOP=1|2: truncate after a phase (timing breakdowns)
+#else
+    constexpr uint32_t profile_stop = 0;  // (one less live scalar in a kernel that spills SGPRs)
+    (void)profile_stop_arg;
+#endif
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t k = db.k;
+    const uint64_t L64 = b1 - b0;
+    auto put_stats = [&](uint32_t nk_, uint32_t nm, uint32_t nr, uint64_t lp) {
+        if (STATS && stats && lane == 0) {
+            uint64_t* s = reinterpret_cast<uint64_t*>(stats + r);
+            s[0] = (uint64_t)nk_ | ((uint64_t)nm << 32);
+            s[1] = (uint64_t)nr;
+            s[2] = lp;
+        }
+    };
+    if (L64 < k) { put_stats(0, 0, 0, 0); write_record(out, r, CLS_ERR_TOO_FEW_KMERS, 0, 0, 0, 0); return; }
+    const uint32_t L = (uint32_t)L64, nf = L - k + 1, nk = 2 * nf;  // nk <= 64*SLOTS by classification
+    // ---- A1/A2. load + validate + 2-bit pack; per k-mer: code -> direct table ----------------------
+    // CANON (an index in which every k-mer and its reverse complement carry the same tip set, i.e. one built from
+    // both strands): the k-mers of window p on the two strands are reverse complements of each other, so ONE lookup
+    // of the smaller of the two answers for both; half the lookups, half the slots.
+    constexpr bool CANON = MODE == 1, HASHED = MODE == 2;  // MODE 0: direct table, both strands looked up
+    constexpr int LS = CANON ? (SLOTS + 1) / 2 : SLOTS;
+    uint4 ent[LS];
+    uint32_t kw[LS];
+    // the wide class sizes its LDS tables by the read (clearing 3 x 2048 entries cost more than placing a 250 bp read)
+    uint32_t tb = SET_BITS;
+    if constexpr (SET_BITS > 9) {
+        const uint32_t want = 2 * (CANON ? nf : nk);
+        tb = 9;
+        while ((1u << tb) < want && tb < (uint32_t)SET_BITS) ++tb;
+        tb = uniform(tb);
+    }
+    bool valid_read;
+    if constexpr (HASHED) valid_read = hash_front<LS, SET_BITS, ADDR32>(db, cx, bases, b0, L, nf, nk, ent, kw, tb);
+    else valid_read = fast_front<LS, SET_BITS, ADDR32>(db, cx, bases, b0, L, nf, CANON ? nf : nk, ent, kw, 32, CANON, tb);
+    if (!valid_read) {
+        put_stats(0, 0, 0, 0);
+        write_record(out, r, CLS_ERR_INVALID_BASE, 0, 0, 0, 0);
+        return;
+    }
+    const uint32_t* __restrict__ recs = db.postings;
+    // distinct hashes: the FIRST k-mer that reaches an entry keeps it (HashSet<u64> semantics)
+#pragma unroll
+    for (int s = 0; s < LS; ++s) {
+        if (ent[s].x != 0) {
+            const uint32_t key = ent[s].x;
+            uint32_t pos = (key * 2654435761u) >> (32 - tb);
+#pragma unroll 1
+            for (;;) {
+                const uint32_t old = atomicCAS(&cx.set[pos], SET_EMPTY, key);
+                if (old == SET_EMPTY) break;
+                if (old == key) { ent[s] = uint4{0u, 0u, 0xFFFFFFFFu, 0u}; kw[s] = 0; break; }
+                pos = (pos + 1) & ((1u << tb) - 1);
+            }
+        }
+    }
+    if (profile_stop == 1) { write_record(out, r, 0xFE, (int32_t)(ent[0].x + ent[LS - 1].x), 0, 0, 0); return; }  // profiling aid
+    // ---- A3. |M|, |M_root| (the descent state comes with the table entry: no header read) -----------------
+    uint32_t cnt = 0;  // |M| in bits 0..15, |M_root| in bits 16..31 (per lane, then summed)
+    uint64_t leafp = 0;
+#pragma unroll
+    for (int s = 0; s < LS; ++s) {
+        if (STATS) leafp += (uint64_t)kw[s] * ldx<uint4, ADDR32>(recs, ent[s].x + 1).x;  // record 1 (the dummy's second half) holds 0
+        cnt += (ent[s].x != 0 ? kw[s] : 0u) + ((ent[s].w >> 31) * kw[s] << 16);
+    }
+    cnt = wave_sum(cnt);
+    const uint32_t n_m = cnt & 0xFFFFu, n_root = cnt >> 16;
+    if (STATS) {
+        for (int o = 32; o > 0; o >>= 1) leafp += ((uint64_t)__shfl_xor((uint32_t)(leafp >> 32), o) << 32) | __shfl_xor((uint32_t)leafp, o);
+        put_stats(nk, n_m, n_root, leafp);
+    }
+    if (profile_stop == 2) { write_record(out, r, 0xFE, (int32_t)(ent[0].z + ent[LS - 1].w), 0, 0, 0); return; }
+    // ---- B. thresholds ------------------------------------------------------------------------------
+    if (n_m == 0) { write_record(out, r, CLS_UNCLASSIFIABLE_NO_MATCH, 0, 0, 0, 0); return; }
+    if (n_root == 0) { write_record(out, r, CLS_UNCLASSIFIABLE_NO_ROOT, 0, 0, 0, 0); return; }
+    // node records through the scalar unit: a DNode is 8 dwords {pre, size, first_child, n_nonleaf, id lo, id hi, split, flags}
+    snode_t P = load_node(db.nodes, 0);
+    if (!(P.s[7] & 1u)) { write_record(out, r, CLS_ERR_ROOT_NO_CHILDREN, 0, 0, 0, 0); return; }
+    {
+        const double expected = round((double)n_m * prm.min_match_coverage);
+        const uint64_t exp_usize = (expected != expected) ? 0ull : (uint64_t)expected;
+        if ((uint64_t)n_root < exp_usize) { write_record(out, r, CLS_UNCLASSIFIABLE_COVERAGE, (int32_t)n_root, 0, 0, 0); return; }
+    }
+    // ---- A4. group the k-mers by tip set ----------------------------------------------------------------
+    // k-mers with the same tip list (they share their split tree: same root split, or the same single tip)
+    // stay together all the way down, so the descent runs on {set, number of k-mers} pairs: a 150 bp read
+    // has a few dozen of them.  The first k-mer to claim a key owns the group; the groups are compacted into
+    // the staging area (64 per chunk; chunk 0 then lives in registers, the others stay in LDS).
+    uint32_t n_sets = 0;
+    {
+        uint32_t pos[LS];
+        uint32_t owner = 0;
+#pragma unroll
+        for (int s = 0; s < LS; ++s) {
+            const uint32_t lo_ = ent[s].z & DIRECT_TIP_MASK, hi_ = ent[s].w & 0x7FFFFFFFu;
+            pos[s] = 0;
+            if (lo_ <= hi_) {  // has tips below the root (absent / tip-less entries hold {MAX, 0})
+                const uint32_t key = ent[s].y ? ent[s].y : (0x80000000u | lo_);
+                uint32_t p = (key * 2654435761u) >> (32 - tb);
+#pragma unroll 1
+                for (;;) {
+                    const uint32_t old = atomicCAS(&cx.gkey[p], SET_EMPTY, key);
+                    if (old == SET_EMPTY) { owner |= 1u << s; break; }
+                    if (old == key) break;
+                    p = (p + 1) & ((1u << tb) - 1);
+                }
+                atomicAdd(&cx.gcnt[p], kw[s]);
+                pos[s] = p;
+            }
+        }
+        wave_sync();
+#pragma unroll
+        for (int s = 0; s < LS; ++s) pos[s] = ((owner >> s) & 1u) ? cx.gcnt[pos[s]] : 0u;  // now: the group's weight
+        wave_sync();  // the tables are dead from here on: the staging area lies over them
+#pragma unroll
+        for (int s = 0; s < LS; ++s) {
+            const uint64_t m = __ballot((owner >> s) & 1u);
+            if ((owner >> s) & 1u)
+                cx.stage[n_sets + popc64(m & ((1ull << lane) - 1))] = uint4{ent[s].z & DIRECT_TIP_MASK, ent[s].w & 0x7FFFFFFFu, ent[s].y, pos[s]};
+            n_sets += popc64(m);
+        }
+    }
+    descend_groups<(SLOTS * 64 < 1024), ADDR32, POLY>(db, prm, cx, n_sets, P, r, out);
 }
 
 template <int SLOTS, int SET_BITS, bool STATS, bool ADDR32, int MODE, bool POLY>
