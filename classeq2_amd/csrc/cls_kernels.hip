@@ -164,6 +164,22 @@ __device__ __forceinline__ void hash_kmer_and_prefix(const uint8_t* p, uint32_t 
     mz_out = mz;
 }
 
+// MurmurHash3_x64_128(p[0..len), seed 0).0 with the message fetched eight bytes at a time (gfx950 reads unaligned
+// 64-bit words from LDS in one ds_read_b64).  Reads up to 15 bytes past the message, inside the caller's LDS buffer.
+__device__ __forceinline__ uint64_t lds_u64(const uint8_t* p) { uint64_t v; __builtin_memcpy(&v, p, 8); return v; }
+__device__ __forceinline__ uint64_t murmur3_h1_lds(const uint8_t* p, uint32_t len) {
+    Mur3 m;
+    const uint32_t nblocks = len >> 4;
+#pragma unroll 1
+    for (uint32_t b = 0; b < nblocks; ++b) m.block(lds_u64(p + 16 * b), lds_u64(p + 16 * b + 8));
+    const uint32_t t = len & 15u;
+    const uint8_t* tail = p + 16 * nblocks;
+    uint64_t k1 = 0, k2 = 0;
+    if (t > 0) { k1 = lds_u64(tail); if (t < 8) k1 &= (1ull << (8 * t)) - 1; }
+    if (t > 8) { k2 = lds_u64(tail + 8) & ((1ull << (8 * (t - 8))) - 1); }
+    return m.finish(k1, k2, t, len);
+}
+
 struct WaveCtx {
     uint8_t* seq;    // LDS: upper-cased read
     uint32_t* set;   // LDS: distinct-hit set (keys = table slot indices)
@@ -278,8 +294,8 @@ __device__ __forceinline__ bool match_phase(const DbDev& db, const WaveCtx& cx, 
         uint32_t tidx = 0;
         uint64_t loc = 0, mz = 0;
         if (j < nk) {
-            uint64_t h;
-            hash_kmer_and_prefix(kmer_start(j), k, m_eff, h, mz);
+            const uint64_t h = murmur3_h1_lds(kmer_start(j), k);  // (eight bytes per LDS read; up to 15 bytes past the k-mer, inside the block's LDS)
+            mz = murmur3_h1_lds(kmer_start(j), m_eff);
             uint64_t idx = h & db.table_mask;
 #pragma unroll 1
             for (;;) {
@@ -1027,22 +1043,6 @@ __device__ __forceinline__ bool fast_front(const DbDev& db, const FastCtx& cx, c
         kw[s] = !take ? 0u : (canonical && !palindrome) ? 2u : 1u;  // canonical: the window stands for the k-mer and its reverse complement
     }
     return true;
-}
-
-// MurmurHash3_x64_128(p[0..len), seed 0).0 with the message fetched eight bytes at a time (gfx950 reads unaligned
-// 64-bit words from LDS in one ds_read_b64).  Reads up to 15 bytes past the message, inside the caller's LDS buffer.
-__device__ __forceinline__ uint64_t lds_u64(const uint8_t* p) { uint64_t v; __builtin_memcpy(&v, p, 8); return v; }
-__device__ __forceinline__ uint64_t murmur3_h1_lds(const uint8_t* p, uint32_t len) {
-    Mur3 m;
-    const uint32_t nblocks = len >> 4;
-#pragma unroll 1
-    for (uint32_t b = 0; b < nblocks; ++b) m.block(lds_u64(p + 16 * b), lds_u64(p + 16 * b + 8));
-    const uint32_t t = len & 15u;
-    const uint8_t* tail = p + 16 * nblocks;
-    uint64_t k1 = 0, k2 = 0;
-    if (t > 0) { k1 = lds_u64(tail); if (t < 8) k1 &= (1ull << (8 * t)) - 1; }
-    if (t > 8) { k2 = lds_u64(tail + 8) & ((1ull << (8 * (t - 8))) - 1); }
-    return m.finish(k1, k2, t, len);
 }
 
 // The same front for an index WITHOUT a direct table (k > 15: the reference's default is k = 35): the read goes to
