@@ -1,20 +1,26 @@
 #!/usr/bin/env python3
 """Headline benchmark: query placements/sec on the 10k-leaf tree, 150 bp reads.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--config C3]
 
 A "step" is one pass of the placement hot path (`cls_place_batch_device`, the
 C-ABI entry a Rust caller would bind) over one batch of synthetic reads that is
 already resident in HBM.  At N=1 the workload is BASELINE.json configs[2]
 ("C3": 10k-leaf tree, 1M x 150 bp reads, k=12).  At N>1 every rank holds the
-same index and its own shard of ONE global read stream (1M reads per GPU ->
-"weak" scaling; configs[3] is this shape), and each step ends with the single
-gather of the 24-byte placement records to rank 0 over RCCL.
+same index and its own shard of ONE global read stream, and each step ends with
+the single gather of the 24-byte placement records to rank 0 over RCCL:
+  * default (C3): 1M reads per GPU -> "weak" scaling;
+  * --config C4 (BASELINE configs[3]): ONE stream of 10M reads, ceil(10M/N) per
+    rank -> "strong" scaling.
+Other --config values are the shapes SURVEY.md 8 / VERDICT name: C2 (1k-leaf,
+k=8), C5 (50k-leaf deep tree, 10 kb reads, k=15), C3s12 / C3s35 (the
+support-collapsed 10k-leaf tree at k=12 and at the reference's default k=35).
 
-Rank 0 prints ONE JSON line; see DESIGN.md "Measurement" for how `roofline` and
-`cpu_baseline` are obtained.
+Rank 0 prints ONE JSON line; DESIGN.md "Measurement" says how `roofline`,
+`host_window` and `cpu_baseline` are obtained.
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -29,51 +35,84 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
 
 
-def algorithmic_bytes(read_lens, stats):
-    """B(q) = L + 16*2(L-k+1) + 4*sum_{h in M(q)} |leaves(h)| + 24."""
+def survey_model_bytes(read_lens, stats):
+    """SURVEY.md 8(d): B(q) = L + 16*2(L-k+1) + 4*sum_{h in M(q)} |leaves(h)| + 24 -- a model that STREAMS posting lists;
+    this index answers membership from 8-byte split halves instead, so the figure exceeds what any launch moves."""
     return int(read_lens.sum()) + 16 * int(stats["n_query_kmers"].astype(np.int64).sum()) + 4 * int(
         stats["leaf_postings"].astype(np.int64).sum()) + 24 * len(stats)
 
 
-def traffic_lookup(config, reads):
-    """HBM bytes per launch of the dominant kernel from the rocprofv3 PMC passes committed under
-    profiles/ (FETCH_SIZE / WRITE_SIZE collected in separate --pmc runs of this same command and
-    corrected as /opt/skills/guides/MI355X_MICROARCH.md prescribes); null if this workload was not profiled."""
+def needed_bytes(read_lens, stats):
+    """Bytes THIS index must touch to place the batch, counted exactly by the statistics kernel
+    (cls_query_stats.index_bytes: table entries, node records, split halves) + per read its bases, its two 8-byte
+    offsets' share (8), its 4-byte entry of the read list and the 24-byte record.  None if the kernels that ran do
+    not count index bytes."""
+    ib = int(stats["index_bytes"].astype(np.int64).sum())
+    if ib == 0:
+        return None
+    return int(read_lens.sum()) + ib + (8 + 4 + 24) * len(stats)
+
+
+def source_sha16():
+    """Fingerprint of the kernel sources a profile belongs to (the GPU box has no .git)."""
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "classeq2_amd", "csrc")
+    for name in sorted(os.listdir(csrc)):
+        if name.endswith((".hip", ".cpp", ".h")):
+            with open(os.path.join(csrc, name), "rb") as f:
+                h.update(name.encode() + b"\0" + f.read())
+    return h.hexdigest()[:16]
+
+
+def traffic_lookup(config, reads, kernel):
+    """HBM bytes per launch of the dominant kernel from the rocprofv3 PMC passes committed under profiles/
+    (FETCH_SIZE / WRITE_SIZE collected in separate --pmc runs of this same command, tools/profile.sh).  An entry
+    only counts when it was taken from THESE sources and THIS kernel instance; otherwise (None, True)."""
     try:
         with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
-            return json.load(f).get(f"{config}:{reads}", {}).get("hbm_bytes_per_launch")
+            e = json.load(f).get(f"{config}:{reads}")
+    except (OSError, ValueError):
+        return None, False
+    if not e:
+        return None, False
+    if e.get("source_sha16") != source_sha16() or e.get("kernel") != kernel:
+        return None, True
+    return e.get("hbm_bytes_per_launch"), False
+
+
+def gather_reference():
+    """Measured random-gather rate of this chip (tools/gather_probe.hip, committed summary), if present."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "gather_probe.json")) as f:
+            return json.load(f)
     except (OSError, ValueError):
         return None
 
 
-def db_kernel_name(db):
-    return "place_fast_kernel<5,9,...>" if db.info.direct_table else "place_split_kernel<5,9,...>"
-
-
-def cpu_baseline(synth, cfg, budget_s=15.0):
-    """The C oracle (oracle/cls_oracle.c, kind "port") on this host's cores, on
-    a bounded prefix of the same read stream."""
+def cpu_baseline(synth, cfg, first, budget_s=15.0):
+    """The C oracle (oracle/cls_oracle.c, kind "port") on this host's cores, on a bounded prefix of the same read
+    stream.  Returns (json object, oracle records of that prefix)."""
     from oracle.oracle_port import OraclePort
 
     cores = min(os.cpu_count() or 1, 64)
     t0 = time.time()
     port = OraclePort(synth.flat)
     build_s = time.time() - t0
-    probe = 2000
-    bases, offsets, _ = synth.reads(probe, cfg["read_len"])
+    probe = max(8, min(2000, cfg["n_reads"]) if cfg["read_len"] <= 1000 else 16)
+    bases, offsets, _ = synth.reads(probe, cfg["read_len"], first=first)
     t0 = time.time()
     port.place_batch(bases, offsets, threads=cores)
     dt = max(time.time() - t0, 1e-4)
     n = int(min(cfg["n_reads"], max(probe, probe * budget_s / dt)))
-    bases, offsets, _ = synth.reads(n, cfg["read_len"])
+    bases, offsets, _ = synth.reads(n, cfg["read_len"], first=first)
     t0 = time.time()
-    port.place_batch(bases, offsets, threads=cores)
+    recs = port.place_batch(bases, offsets, threads=cores)
     dt = time.time() - t0
     # what the unmodified Rust path would cost: the port + the reference's per-query deep clone of the index
     # (place_sequence.rs:77-80) and per-bucket key-set rebuild (kmers_map.rs:58-62); an estimate, on a small sample
     port.set_reference_cost(True)
     rc_threads = min(cores, 16)  # (3 M allocations per query: more threads only fight over the allocator)
-    m = 2 * rc_threads
+    m = min(n, 2 * rc_threads)
     t0 = time.time()
     port.place_batch(bases[: m * cfg["read_len"]], offsets[: m + 1], threads=rc_threads)
     dt_ref = time.time() - t0
@@ -85,7 +124,37 @@ def cpu_baseline(synth, cfg, budget_s=15.0):
                                     "sample": f"first {m} reads, {dt_ref:.1f} s wall",
                                     "what": "the port plus the reference's per-query index clone and bucket key-set rebuild "
                                             "(place_sequence.rs:77-80, kmers_map.rs:58-62); an estimate, not the Rust binary"},
-    }
+    }, recs
+
+
+def host_window(db, bases, offsets, n, reps=5):
+    """SURVEY.md 8(d) window (i): `cls_place_batch` enter -> return, host buffers in, host records out (H2D of the
+    reads, every kernel, D2H of the records; mod.rs:64-67 / 264-267 minus the file stages).  Median of `reps`
+    after one warm-up, with pinned and with pageable host memory."""
+    import torch
+
+    from classeq2_amd import _abi
+
+    res = {}
+    for kind in ("pinned", "pageable"):
+        if kind == "pinned":
+            hb = torch.from_numpy(bases).pin_memory()
+            ho = torch.from_numpy(offsets.view(np.int64)).pin_memory()
+            hout = torch.zeros(n * 24, dtype=torch.uint8).pin_memory()
+            b, o, out = hb.numpy(), ho.numpy().view(np.uint64), hout.numpy().view(_abi.PLACEMENT_DTYPE)
+        else:
+            b, o, out = bases, offsets, np.zeros(n, dtype=_abi.PLACEMENT_DTYPE)
+        times = []
+        for i in range(reps + 1):
+            t0 = time.perf_counter()
+            db.place_batch(b, o, out=out)
+            times.append((time.perf_counter() - t0) * 1e3)
+        ms = float(np.median(times[1:]))
+        res[kind] = {"ms": ms, "placements_per_s": n / (ms * 1e-3)}
+        last = out.copy()
+    res["what"] = (f"cls_place_batch (host buffers -> host records) on the same {n} reads, median of {reps} after 1 warm-up; "
+                   "`value` above is the device-resident window (cls_place_batch_device)")
+    return res, last
 
 
 def main():
@@ -93,9 +162,13 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--config", default="C3", choices=["C2", "C3"])
-    ap.add_argument("--reads", type=int, default=0, help="reads per GPU (default: the config's)")
+    ap.add_argument("--config", default="C3", choices=["C2", "C3", "C4", "C5", "C3s12", "C3s35"])
+    ap.add_argument("--reads", type=int, default=0, help="reads per GPU (default: the config's; C4: total reads of the stream)")
+    ap.add_argument("--scale", type=float, default=1.0, help="C5 only: fraction of the 50k leaves / 1M reads to run")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-host-window", action="store_true")
+    ap.add_argument("--dump-records", default="", help="rank 0 writes the records it holds after the last step (all ranks' "
+                    "shards in rank order at N > 1) to this .npy file: lets a test check the gathered records against the oracle")
     args = ap.parse_args()
 
     import torch
@@ -126,18 +199,34 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
 
     cfg = dict(CONFIGS[args.config])
-    per_gpu = args.reads or cfg["n_reads"]
+    strong = args.config == "C4"  # one stream of fixed size split over the ranks
+    if args.config == "C5" and args.scale != 1.0:
+        cfg["n_leaves"] = max(64, int(cfg["n_leaves"] * args.scale))
+        cfg["n_reads"] = max(64, int(cfg["n_reads"] * args.scale))
+    if strong:
+        total_reads = args.reads or cfg["n_reads"]
+        per_gpu = (total_reads + world - 1) // world          # contiguous ceil(N/G) blocks
+        first = rank * per_gpu
+        mine = max(0, min(per_gpu, total_reads - first))
+    else:
+        per_gpu = mine = args.reads or cfg["n_reads"]
+        total_reads = per_gpu * world
+        first = rank * per_gpu
     cfg["n_reads"] = per_gpu
     threads = max(1, (os.cpu_count() or 8) // max(1, min(world, 8)))
     t0 = time.time()
     synth = SynthDb(cfg["n_leaves"], cfg["ref_len"], cfg["k_size"], cfg["m_size"], deep=cfg["deep"],
-                    max_depth=cfg["max_depth"], threads=threads)
+                    max_depth=cfg["max_depth"], collapse_prob=cfg.get("collapse_prob", 0.0), threads=threads,
+                    tips_only=cfg.get("tips_only", False))
     gen_s = time.time() - t0
     t0 = time.time()
     db = engine.PlacementDb(synth.flat, device=local_rank)
     create_s = time.time() - t0
-    # this rank's shard of the global read stream (seed 3)
-    bases, offsets, _ = synth.reads(per_gpu, cfg["read_len"], seed=3, first=rank * per_gpu)
+    if cfg["read_len"] > 4096:
+        db.set_max_read_len(cfg["read_len"])
+    # this rank's shard of the global read stream (seed 3); every rank allocates per_gpu records so that the
+    # gather has one shape (the last shard of a strong-scaling split may be shorter: its tail stays zero)
+    bases, offsets, _ = synth.reads(max(mine, 1), cfg["read_len"], seed=3, first=first)
     d_bases = torch.from_numpy(bases).to(dev)
     d_off = torch.from_numpy(offsets.view(np.int64)).to(dev)
     d_outs = [torch.zeros(per_gpu * 24, dtype=torch.uint8, device=dev) for _ in range(2)]  # double-buffered records
@@ -146,19 +235,23 @@ def main():
     gathered = [[torch.empty_like(d_out) for _ in range(world)] for _ in range(2)] if (world > 1 and rank == 0) else [None, None]
     stream = torch.cuda.current_stream().cuda_stream
     pending = [None, None]  # the gather still reading each buffer
+    host_gathered = [None]
 
     def step(stats_ptr=0, buf=0):
         if pending[buf] is not None:  # the records of two steps ago must have left before they are overwritten
             pending[buf].wait()
             pending[buf] = None
-        db.place_batch_device(d_bases.data_ptr(), d_off.data_ptr(), per_gpu, d_outs[buf].data_ptr(), None, stats_ptr, stream)
+        if mine:
+            db.place_batch_device(d_bases.data_ptr(), d_off.data_ptr(), mine, d_outs[buf].data_ptr(), None, stats_ptr, stream)
 
     def gather_records(buf=0):
         """The path's one collective: every rank's placement records -> rank 0 (RCCL over xGMI), asynchronous:
         the gather of step i runs while step i+1 places into the other buffer."""
         if rehearsal:
             h = d_outs[buf].cpu()
-            dist.gather(h, [torch.empty_like(h) for _ in range(world)] if rank == 0 else None, dst=0)
+            lst = [torch.empty_like(h) for _ in range(world)] if rank == 0 else None
+            dist.gather(h, lst, dst=0)
+            host_gathered[0] = lst
         else:
             pending[buf] = dist.gather(d_outs[buf], gathered[buf], dst=0, async_op=True)
 
@@ -172,11 +265,13 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # untimed: per-query counters for the algorithmic-byte figure
+    # untimed: per-query counters for the byte accounting
     step(d_stats.data_ptr())
     torch.cuda.synchronize()
-    stats = d_stats.cpu().numpy().view(_abi.STATS_DTYPE)
-    alg_bytes = algorithmic_bytes(np.diff(offsets.astype(np.int64)), stats)
+    stats = d_stats.cpu().numpy().view(_abi.STATS_DTYPE)[:mine]
+    lens = np.diff(offsets.astype(np.int64))[:mine]
+    model_bytes = survey_model_bytes(lens, stats)
+    need = needed_bytes(lens, stats)
     ref_out = d_out.cpu().numpy().view(_abi.PLACEMENT_DTYPE).copy()
 
     for i in range(args.warmup):
@@ -207,15 +302,22 @@ def main():
     if not os.environ.get("CLS_PROFILE_STOP"):
         for f in ("status", "one", "rest", "levels", "clade_id"):
             assert (now[f] == ref_out[f]).all(), "non-deterministic placement records"
+    slots = db.refresh_info().scratch_slots
 
     if rank == 0:
-        total = per_gpu * world * args.steps
-        achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
-        traffic = traffic_lookup(args.config, per_gpu)
-        counts = np.bincount(ref_out["status"], minlength=12)[:12]  # (a CLS_PROFILE_STOP run writes junk statuses)
+        total = total_reads * args.steps
+        kname = db.kernel_name()
+        traffic, stale = traffic_lookup(args.config, mine, kname)
+        counts = np.bincount(ref_out["status"][:mine], minlength=12)[:12]  # (a CLS_PROFILE_STOP run writes junk statuses)
+        ksec = kernel_ms * 1e-3 if kernel_ms > 0 else float("nan")
+        achieved = (need / ksec / 1e9) if need else None
+        metric = {"C3": "query placements/sec, 10k-leaf tree, 150 bp reads", "C4": "query placements/sec, 10k-leaf tree, 150 bp reads",
+                  "C2": "query placements/sec, 1k-leaf tree, 150 bp reads",
+                  "C5": "query placements/sec, 50k-leaf deep tree, 10 kb reads",
+                  "C3s12": "query placements/sec, support-collapsed 10k-leaf tree, 150 bp reads",
+                  "C3s35": "query placements/sec, support-collapsed 10k-leaf tree, 150 bp reads, k=35"}[args.config]
         line = {
-            "metric": "query placements/sec, 10k-leaf tree, 150 bp reads" if args.config == "C3"
-            else "query placements/sec, 1k-leaf tree, 150 bp reads",
+            "metric": metric,
             "value": total / elapsed,
             "unit": "placements/s",
             "n_gpus": world,
@@ -223,35 +325,72 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if strong else "weak",
             "vs_baseline": None,
             "dtype": "u64",
             "data": "synthetic" + (" (REHEARSAL: all ranks on one GPU, gloo; not a measurement)" if rehearsal else ""),
+            "window": "device-resident: reads in HBM -> records in HBM (cls_place_batch_device, every kernel of the call"
+                      + (" + the gather to rank 0" if world > 1 else "") + "); the host-buffer window is `host_window`",
             "config": {
-                "workload": f"{args.config}: {cfg['n_leaves']}-leaf Yule tree, {per_gpu} x {cfg['read_len']} bp reads per GPU, "
-                            f"k={cfg['k_size']}, m={cfg['m_size']} (seeds tree=1 refseq=2 reads=3)",
+                "workload": f"{args.config}: {cfg['n_leaves']}-leaf {'deep (depth <= %d) ' % cfg['max_depth'] if cfg['deep'] else ''}"
+                            f"{'support-collapsed ' if cfg.get('collapse_prob') else ''}tree, "
+                            + (f"{total_reads} x {cfg['read_len']} bp reads in ONE stream, ceil(N/G) = {per_gpu} per GPU, " if strong
+                               else f"{per_gpu} x {cfg['read_len']} bp reads per GPU, ")
+                            + f"k={cfg['k_size']}, m={cfg['m_size']} (seeds tree=1 refseq=2 reads=3)",
                 "reads_per_gpu": per_gpu,
                 "parallelism": f"reads sharded x{world}, index replicated, 1 gather/step" if world > 1 else "single GPU",
                 "index": {"n_nodes": int(db.info.n_nodes), "n_kmers": int(db.info.n_kmers), "n_tip_sets": int(db.info.n_tip_sets), "max_depth": int(db.info.max_depth),
-                          "hbm_bytes": int(db.info.hbm_bytes)},
+                          "hbm_bytes": int(db.info.hbm_bytes), "input": "tips only" if cfg.get("tips_only") else "explicit node sets"},
                 "status_counts": {_abi.STATUS_NAMES[i]: int(c) for i, c in enumerate(counts) if c},
-                "mean_levels": float(ref_out["levels"].mean()),
+                "mean_levels": float(ref_out["levels"][:mine].mean()) if mine else 0.0,
                 "setup_s": {"generate": round(gen_s, 1), "db_create": round(create_s, 1)},
+                "scratch_slots": int(slots),
             },
             "roofline": {
-                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                # the index answers set membership without streaming the posting lists the algorithmic figure
-                # prices, so `frac` exceeds 1; the bytes the kernel really moved, against the same peak:
-                "traffic_frac": (traffic / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
-                "kernel": db_kernel_name(db), "kernel_ms": kernel_ms, "kernel_launches_timed": int(k_cnt),
+                "bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                # bytes this index must touch (counted by the statistics kernel) / time of the dominant kernel
+                "achieved": achieved, "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
+                "needed_bytes_per_launch": need, "needed_bytes_per_read": (need / mine) if need and mine else None,
+                # bytes the kernel really moved (rocprofv3 FETCH_SIZE + WRITE_SIZE of a profile of THESE sources), else null
+                "traffic": traffic, "traffic_stale": stale,
+                "traffic_frac": (traffic / ksec / 1e9 / HBM_PEAK_GBS) if traffic else None,
+                "overfetch": (traffic / need) if traffic and need else None,
+                "kernel": kname, "kernel_ms": kernel_ms, "kernel_launches_timed": int(k_cnt),
+                "kernels_timed": "kernel_ms = the wave-per-read placement kernel of the <= 320-k-mer class only (HIP events on "
+                                 "the launch stream); call_ms = the whole call: locality keys + sort + classify + every class",
                 "call_ms": call_ms,
-                "algorithmic_bytes_per_launch": alg_bytes,
-                "algorithmic_bytes_per_read": alg_bytes / per_gpu,
+                # SURVEY.md 8(d)'s model prices streamed posting lists; > 1 by construction for an index that never streams them
+                "survey_model_bytes": model_bytes, "survey_model_frac": model_bytes / ksec / 1e9 / HBM_PEAK_GBS,
+                "gather_reference": gather_reference(),
             },
         }
+        if args.dump_records:
+            last = (args.steps - 1) & 1
+            if world == 1:
+                allrec = now.copy()
+            elif rehearsal:
+                allrec = np.concatenate([x.numpy() for x in host_gathered[0]]).view(_abi.PLACEMENT_DTYPE)
+            else:
+                allrec = np.concatenate([x.cpu().numpy() for x in gathered[last]]).view(_abi.PLACEMENT_DTYPE)
+            if strong:  # drop the zero tail of a short last shard
+                allrec = allrec[:total_reads]
+            np.save(args.dump_records, allrec)
+            line["config"]["dumped_records"] = int(len(allrec))
+        if not args.no_host_window and world == 1 and mine:
+            hw, host_recs = host_window(db, bases, offsets, mine)
+            for f in ("status", "one", "rest", "levels", "clade_id"):
+                assert (host_recs[f] == ref_out[f][:mine]).all(), "host-buffer entry disagrees with the device-buffer entry"
+            line["host_window"] = hw
         if not args.no_cpu_baseline and world == 1:  # rank 0 at N=1 only
-            line["cpu_baseline"] = cpu_baseline(synth, cfg)
+            cb, oracle_recs = cpu_baseline(synth, cfg, first)
+            n_chk = min(len(oracle_recs), mine)
+            for f in ("status", "one", "rest", "levels", "clade_id"):
+                bad = np.nonzero(oracle_recs[f][:n_chk] != ref_out[f][:n_chk])[0]
+                if len(bad):
+                    raise SystemExit(f"PARITY FAILURE: read {bad[0]} field {f}: GPU {ref_out[f][bad[0]]} oracle {oracle_recs[f][bad[0]]} "
+                                     f"({len(bad)} of {n_chk} reads differ)")
+            line["cpu_baseline"] = cb
+            line["parity_checked_reads"] = int(n_chk)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

@@ -97,7 +97,7 @@ class QueryStats(C.Structure):
         ("n_query_kmers", C.c_uint32),
         ("n_matched", C.c_uint32),
         ("n_with_root", C.c_uint32),
-        ("pad_", C.c_uint32),
+        ("index_bytes", C.c_uint32),
         ("leaf_postings", C.c_uint64),
     ]
 
@@ -121,6 +121,8 @@ class DbInfo(C.Structure):
         ("binary_tree", C.c_uint32),
         ("direct_table", C.c_uint32),
         ("n_tip_sets", C.c_uint32),
+        ("scratch_slots", C.c_uint32),
+        ("pad_", C.c_uint32),
     ]
 
 
@@ -187,6 +189,6 @@ PLACEMENT_DTYPE = np.dtype(
     [("status", "u1"), ("pad_", "u1", (3,)), ("one", "<i4"), ("rest", "<i4"), ("levels", "<u4"), ("clade_id", "<u8")]
 )
 STATS_DTYPE = np.dtype(
-    [("n_query_kmers", "<u4"), ("n_matched", "<u4"), ("n_with_root", "<u4"), ("pad_", "<u4"), ("leaf_postings", "<u8")]
+    [("n_query_kmers", "<u4"), ("n_matched", "<u4"), ("n_with_root", "<u4"), ("index_bytes", "<u4"), ("leaf_postings", "<u8")]
 )
 assert NODE_DTYPE.itemsize == 32 and PLACEMENT_DTYPE.itemsize == 24 and STATS_DTYPE.itemsize == 24

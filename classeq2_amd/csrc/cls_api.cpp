@@ -2,12 +2,14 @@
 // the host-buffer and device-buffer batch entry points.  Nothing unwinds across
 // the boundary; every failure leaves a thread-local message for cls_last_error().
 #include <hip/hip_runtime.h>
+#include <stdio.h>
 #include <string.h>
 
 #include <algorithm>
 #include <mutex>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "cls_db.h"
@@ -34,12 +36,21 @@ struct Workspace {
     uint32_t* ptr = nullptr;
     uint64_t words = 0;
     hipEvent_t done = nullptr;
-    hipEvent_t t0 = nullptr, t1 = nullptr;  // around the dominant kernel of the launch that used this slot
-    bool timed = false;                     // t0/t1 hold an un-harvested measurement
+    hipStream_t stream = nullptr;           // stream of the slot's last user: the next launch on the SAME stream is ordered
+                                            // behind it and may take the slot at once
+    uint64_t seq = 0;                       // acquisition counter (the oldest busy slot is the one to wait for)
+    int launching = 0;                      // callers between acquire and their `done` record
     bool busy = false;
     bool recorded = false;                  // `done` has been recorded for the current user (until then the event still
                                             // shows the PREVIOUS launch as complete: the slot must not be reclaimed)
 };
+// HIP events around the dominant kernel of one launch (cls_db_kernel_time); pooled, independent of the scratch slots
+struct TimedPair {
+    hipEvent_t t0 = nullptr, t1 = nullptr;
+    bool pending = false;                   // recorded, not yet folded into the handle's accumulators
+};
+constexpr size_t MAX_WS_SLOTS = 8;          // scratch slots per handle; beyond it a caller waits for the oldest launch
+constexpr size_t MAX_TIMED_PAIRS = 256;     // launches in flight whose kernel time is still to be harvested
 
 // Stream + device staging buffers of one host-buffer call, recycled across calls (a hipMalloc / hipFree / stream
 // create per call cost milliseconds -- and hipFree synchronises the device, stalling every other caller).
@@ -79,10 +90,13 @@ struct cls_db {
     void* d_direct = nullptr;
     void* d_ftable = nullptr;
     std::mutex ws_mu;
-    uint64_t max_read_len = 16384;  // what the device-buffer entry provisions its long-read slices for
+    uint64_t max_read_len = 0;  // what the device-buffer entry provisions its long-read slices for (0: none, reads of up to
+                                // MAX_READ_KMERS k-mers only; cls_db_set_max_read_len opts in)
     double kernel_ms_sum = 0.0;
     uint64_t kernel_launches = 0;
     std::vector<Workspace> ws;  // per-call scratch (class lists, child counters), recycled once their launch has finished
+    std::vector<TimedPair> timed;
+    uint64_t ws_seq = 0;
     std::vector<CallSlot> calls;  // host-buffer calls: stream + staging buffers (ws_mu)
 };
 
@@ -103,10 +117,12 @@ extern "C" void cls_db_destroy(cls_db* db) {
     bool have_prev = hipGetDevice(&prev) == hipSuccess;
     (void)hipSetDevice(db->device);
     for (auto& w : db->ws) {
-        if (w.done) { (void)hipEventSynchronize(w.done); (void)hipEventDestroy(w.done); }
-        if (w.t0) (void)hipEventDestroy(w.t0);
-        if (w.t1) (void)hipEventDestroy(w.t1);
+        if (w.done) { if (w.recorded) (void)hipEventSynchronize(w.done); (void)hipEventDestroy(w.done); }
         if (w.ptr) (void)hipFree(w.ptr);
+    }
+    for (auto& t : db->timed) {
+        if (t.t0) (void)hipEventDestroy(t.t0);
+        if (t.t1) (void)hipEventDestroy(t.t1);
     }
     for (auto& c : db->calls) {
         if (c.stream) { (void)hipStreamSynchronize(c.stream); (void)hipStreamDestroy(c.stream); }
@@ -222,37 +238,97 @@ extern "C" int cls_db_validate(const cls_db_desc* d) {
 
 extern "C" int cls_db_info_get(const cls_db* db, cls_db_info* info) {
     if (!db || !info) return fail(CLS_E_INVALID_ARG, "cls_db_info_get: null argument");
+    cls_db* mdb = const_cast<cls_db*>(db);
+    std::lock_guard<std::mutex> g(mdb->ws_mu);
     *info = db->info;
+    info->scratch_slots = (uint32_t)db->ws.size();
     return CLS_OK;
 }
 
-// fold a finished slot's kernel timing into the handle's accumulators (ws_mu held)
-static void harvest(cls_db* db, Workspace& w) {
-    if (!w.timed) return;
-    float ms = 0.f;
-    if (hipEventElapsedTime(&ms, w.t0, w.t1) == hipSuccess) { db->kernel_ms_sum += ms; db->kernel_launches++; }
-    w.timed = false;
+// fold finished kernel timings into the handle's accumulators (ws_mu held); `wait`: also those still running
+static void harvest(cls_db* db, bool wait) {
+    for (auto& t : db->timed) {
+        if (!t.pending) continue;
+        if (wait ? hipEventSynchronize(t.t1) != hipSuccess : hipEventQuery(t.t1) != hipSuccess) continue;
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, t.t0, t.t1) == hipSuccess) { db->kernel_ms_sum += ms; db->kernel_launches++; }
+        t.pending = false;
+    }
 }
 
-// Take (or add) a scratch workspace whose previous user has finished.
+// An event pair for one launch's dominant kernel (ws_mu held); SIZE_MAX: none free, the launch goes untimed.
+static size_t acquire_timed(cls_db* db) {
+    harvest(db, false);
+    for (size_t i = 0; i < db->timed.size(); ++i)
+        if (!db->timed[i].pending && db->timed[i].t0) { db->timed[i].pending = false; return i; }
+    if (db->timed.size() >= MAX_TIMED_PAIRS) return SIZE_MAX;
+    TimedPair t;
+    if (hipEventCreate(&t.t0) != hipSuccess) return SIZE_MAX;
+    if (hipEventCreate(&t.t1) != hipSuccess) { (void)hipEventDestroy(t.t0); return SIZE_MAX; }
+    db->timed.push_back(t);
+    return db->timed.size() - 1;
+}
+
+// Take a scratch workspace for a launch on `stream`:
+//  * a slot whose last user ran on the SAME stream is taken at once (stream order makes the reuse safe), so a caller
+//    that pipelines many batches on one stream keeps ONE slot however far ahead of the device it runs;
+//  * else a slot whose launch has finished;
+//  * else a new one, up to MAX_WS_SLOTS; beyond that the caller waits for the oldest launch in flight.
+// Idle slots that are too small are freed before a larger one is allocated.
 // `*use` = a copy of the slot taken under the lock: the vector may grow (and move) while the caller launches.
-static int acquire_ws(cls_db* db, uint64_t words, size_t* slot, Workspace* use) {
-    std::lock_guard<std::mutex> g(db->ws_mu);
-    for (size_t i = 0; i < db->ws.size(); ++i) {
-        Workspace& w = db->ws[i];
-        if (w.busy && w.recorded && hipEventQuery(w.done) == hipSuccess) { w.busy = false; harvest(db, w); }
-        if (!w.busy && w.words >= words) { w.busy = true; w.recorded = false; *slot = i; *use = w; return CLS_OK; }
+static int acquire_ws(cls_db* db, uint64_t words, hipStream_t stream, size_t* slot, Workspace* use) {
+    std::unique_lock<std::mutex> g(db->ws_mu);
+    for (;;) {
+        size_t oldest = SIZE_MAX;
+        for (size_t i = 0; i < db->ws.size(); ++i) {
+            Workspace& w = db->ws[i];
+            if (w.busy && w.recorded && w.launching == 0 && hipEventQuery(w.done) == hipSuccess) w.busy = false;
+            const bool same_stream = w.busy && w.recorded && w.launching == 0 && w.stream == stream;
+            if ((!w.busy || same_stream) && w.words >= words) {
+                w.busy = true; w.recorded = false; w.launching = 1; w.stream = stream; w.seq = ++db->ws_seq;
+                *slot = i; *use = w;
+                return CLS_OK;
+            }
+            if (w.busy && w.recorded && w.launching == 0 && (oldest == SIZE_MAX || w.seq < db->ws[oldest].seq)) oldest = i;
+        }
+        // nothing fits: drop idle slots (they are too small), then grow or wait
+        for (size_t i = 0; i < db->ws.size();) {
+            Workspace& w = db->ws[i];
+            if (!w.busy) {
+                (void)hipEventDestroy(w.done);
+                (void)hipFree(w.ptr);
+                db->ws.erase(db->ws.begin() + (ptrdiff_t)i);
+                oldest = SIZE_MAX;  // (indices moved: recomputed on the next round if needed)
+            } else ++i;
+        }
+        if (db->ws.size() < MAX_WS_SLOTS) break;
+        if (oldest == SIZE_MAX) {
+            for (size_t i = 0; i < db->ws.size(); ++i)
+                if (db->ws[i].busy && db->ws[i].recorded && db->ws[i].launching == 0 && (oldest == SIZE_MAX || db->ws[i].seq < db->ws[oldest].seq)) oldest = i;
+        }
+        if (oldest == SIZE_MAX) {  // every slot is between acquire and record on another thread: let them get on
+            g.unlock();
+            std::this_thread::yield();
+            g.lock();
+            continue;
+        }
+        hipEvent_t ev = db->ws[oldest].done;
+        g.unlock();
+        if (hipEventSynchronize(ev) != hipSuccess) return fail(CLS_E_HIP, "hipEventSynchronize failed while waiting for a scratch slot");
+        g.lock();
     }
     Workspace w;
     if (hipMalloc((void**)&w.ptr, words * 4) != hipSuccess) return fail(CLS_E_NOMEM, "scratch workspace allocation failed");
-    if (hipEventCreateWithFlags(&w.done, hipEventDisableTiming) != hipSuccess || hipEventCreate(&w.t0) != hipSuccess ||
-        hipEventCreate(&w.t1) != hipSuccess) {
+    if (hipEventCreateWithFlags(&w.done, hipEventDisableTiming) != hipSuccess) {
         (void)hipFree(w.ptr);
         return fail(CLS_E_HIP, "hipEventCreate failed");
     }
     w.words = words;
     w.busy = true;
     w.recorded = false;
+    w.launching = 1;
+    w.stream = stream;
+    w.seq = ++db->ws_seq;
     db->ws.push_back(w);
     *slot = db->ws.size() - 1;
     *use = w;
@@ -279,15 +355,34 @@ static int place_device(cls_db* db, const void* d_bases, const void* d_offsets, 
     const cls::PlacePlan plan = cls::plan_place(db->dev, n, (uint32_t)db->n_cu, d_stats != nullptr, long_cap, n_long);
     size_t slot = 0;
     Workspace use;
-    int rc = acquire_ws(db, (plan.ws_bytes + 3) / 4, &slot, &use);
+    int rc = acquire_ws(db, (plan.ws_bytes + 3) / 4, stream, &slot, &use);
     if (rc != CLS_OK) return rc;
-    hipError_t e = cls::launch_place(db->dev, prm, plan, (const uint8_t*)d_bases, (const uint64_t*)d_offsets, n,
-                                     (cls_placement*)d_out, (cls_query_stats*)d_stats, use.ptr, stream, use.t0, use.t1);
+    size_t tp = SIZE_MAX;
+    hipEvent_t t0 = nullptr, t1 = nullptr;
     {
         std::lock_guard<std::mutex> g(db->ws_mu);
-        db->ws[slot].timed = (e == hipSuccess);
-        if (hipEventRecord(db->ws[slot].done, stream) != hipSuccess) { db->ws[slot].busy = false; db->ws[slot].timed = false; }
-        db->ws[slot].recorded = true;
+        tp = acquire_timed(db);
+        if (tp != SIZE_MAX) { t0 = db->timed[tp].t0; t1 = db->timed[tp].t1; }
+    }
+    hipError_t e = cls::launch_place(db->dev, prm, plan, (const uint8_t*)d_bases, (const uint64_t*)d_offsets, n,
+                                     (cls_placement*)d_out, (cls_query_stats*)d_stats, use.ptr, stream, t0, t1);
+    bool record_failed = false;
+    {
+        std::lock_guard<std::mutex> g(db->ws_mu);
+        if (tp != SIZE_MAX) db->timed[tp].pending = (e == hipSuccess);
+        // (another thread may have grown the vector meanwhile; slots are only erased while idle, never this one)
+        for (size_t i = 0; i < db->ws.size(); ++i)
+            if (db->ws[i].ptr == use.ptr) { slot = i; break; }
+        record_failed = hipEventRecord(db->ws[slot].done, stream) != hipSuccess;
+    }
+    if (record_failed) (void)hipStreamSynchronize(stream);  // the kernels may still be running: drain before the slot is handed on
+    {
+        std::lock_guard<std::mutex> g(db->ws_mu);
+        for (size_t i = 0; i < db->ws.size(); ++i)
+            if (db->ws[i].ptr == use.ptr) { slot = i; break; }
+        db->ws[slot].launching = 0;
+        db->ws[slot].recorded = !record_failed;
+        if (record_failed) db->ws[slot].busy = false;
     }
     if (e != hipSuccess) return fail(CLS_E_HIP, std::string("kernel launch failed: ") + hipGetErrorString(e));
     return CLS_OK;
@@ -298,24 +393,39 @@ extern "C" int cls_place_batch_device(cls_db* db, const void* d_bases, const voi
     if (!db) return fail(CLS_E_INVALID_ARG, "cls_place_batch_device: null handle");
     if (n == 0) return CLS_OK;
     if (!d_offsets || !d_out) return fail(CLS_E_INVALID_ARG, "cls_place_batch_device: null buffer");
+    // the handle's device must be current for the scratch allocation, the events and the launches
+    int prev = 0;
+    CLS_HIP(hipGetDevice(&prev));
+    if (prev != db->device) CLS_HIP(hipSetDevice(db->device));
+    int rc;
     try {
         uint64_t max_len;
         { std::lock_guard<std::mutex> g(db->ws_mu); max_len = db->max_read_len; }
-        // the read lengths are only known on the device: provision for the handle's limit
-        return place_device(db, d_bases, d_offsets, n, params, d_out, d_stats, (hipStream_t)hip_stream, (uint32_t)(2 * max_len), n);
+        // the read lengths are only known on the device: provision for the handle's limit (0: the register-resident
+        // kernels only -- the long-read slices are provisioned when the caller opts in, cls_db_set_max_read_len)
+        rc = place_device(db, d_bases, d_offsets, n, params, d_out, d_stats, (hipStream_t)hip_stream, (uint32_t)(2 * max_len), max_len ? n : 0);
     } catch (...) {
-        return fail(CLS_E_INTERNAL, "cls_place_batch_device: unknown exception");
+        rc = fail(CLS_E_INTERNAL, "cls_place_batch_device: unknown exception");
+    }
+    if (prev != db->device) (void)hipSetDevice(prev);
+    return rc;
+}
+
+extern "C" int cls_db_kernel_name(const cls_db* db, char* buf, size_t len) {
+    if (!db || !buf || !len) return fail(CLS_E_INVALID_ARG, "cls_db_kernel_name: null argument");
+    try {
+        const std::string s = cls::dominant_kernel_name(db->dev, false);
+        snprintf(buf, len, "%s", s.c_str());
+        return CLS_OK;
+    } catch (...) {
+        return fail(CLS_E_INTERNAL, "cls_db_kernel_name: unknown exception");
     }
 }
 
 extern "C" int cls_db_kernel_time(cls_db* db, double* sum_ms, uint64_t* launches, int reset) {
     if (!db) return fail(CLS_E_INVALID_ARG, "cls_db_kernel_time: null handle");
     std::lock_guard<std::mutex> g(db->ws_mu);
-    for (auto& w : db->ws) {
-        if (w.busy && !w.recorded) continue;  // a launch in progress on another thread: its time is harvested later
-        if (w.busy) { if (hipEventSynchronize(w.done) != hipSuccess) return fail(CLS_E_HIP, "hipEventSynchronize failed"); w.busy = false; }
-        harvest(db, w);
-    }
+    harvest(db, true);
     if (sum_ms) *sum_ms = db->kernel_ms_sum;
     if (launches) *launches = db->kernel_launches;
     if (reset) { db->kernel_ms_sum = 0.0; db->kernel_launches = 0; }

@@ -10,22 +10,35 @@
 
 #include <algorithm>
 #include <atomic>
+#include <exception>
 #include <functional>
+#include <mutex>
 #include <thread>
 
 namespace cls {
 
 namespace {
 
+// An exception inside a worker thread would terminate the process: the workers catch, the caller rethrows
+// after the join (encode_db's callers turn it into CLS_E_NOMEM / CLS_E_INTERNAL).
+struct WorkerError {
+    std::mutex mu;
+    std::exception_ptr first;
+    void capture() { std::lock_guard<std::mutex> g(mu); if (!first) first = std::current_exception(); }
+    void rethrow() { if (first) std::rethrow_exception(first); }
+};
+
 void parallel_chunks(uint64_t n, unsigned n_threads, const std::function<void(unsigned, uint64_t, uint64_t)>& fn) {
     if (n_threads <= 1 || n < 4096) {
         fn(0, 0, n);
         return;
     }
+    WorkerError we;
     std::vector<std::thread> th;
     for (unsigned t = 0; t < n_threads; ++t)
-        th.emplace_back([=, &fn] { fn(t, n * t / n_threads, n * (t + 1) / n_threads); });
+        th.emplace_back([=, &fn, &we] { try { fn(t, n * t / n_threads, n * (t + 1) / n_threads); } catch (...) { we.capture(); } });
     for (auto& x : th) x.join();
+    we.rethrow();
 }
 
 // sort `v` with `cmp` on up to n_threads threads: sorted runs, then pairwise merges
@@ -36,16 +49,21 @@ void parallel_sort(std::vector<T>& v, unsigned n_threads, Cmp cmp) {
     while (parts * 2 <= n_threads && n / (parts * 2) >= 65536) parts *= 2;
     if (parts == 1) { std::sort(v.begin(), v.end(), cmp); return; }
     auto bound = [&](unsigned i) { return v.begin() + (ptrdiff_t)(n * i / parts); };
+    WorkerError we;
     {
         std::vector<std::thread> th;
-        for (unsigned i = 0; i < parts; ++i) th.emplace_back([&, i] { std::sort(bound(i), bound(i + 1), cmp); });
+        for (unsigned i = 0; i < parts; ++i) th.emplace_back([&, i] { try { std::sort(bound(i), bound(i + 1), cmp); } catch (...) { we.capture(); } });
         for (auto& x : th) x.join();
     }
+    we.rethrow();
     for (unsigned width = 1; width < parts; width *= 2) {
         std::vector<std::thread> th;
         for (unsigned i = 0; i + width < parts; i += 2 * width)
-            th.emplace_back([&, i, width] { std::inplace_merge(bound(i), bound(i + width), bound(std::min(parts, i + 2 * width)), cmp); });
+            th.emplace_back([&, i, width] {
+                try { std::inplace_merge(bound(i), bound(i + width), bound(std::min(parts, i + 2 * width)), cmp); } catch (...) { we.capture(); }  // (inplace_merge allocates a buffer)
+            });
         for (auto& x : th) x.join();
+        we.rethrow();
     }
 }
 

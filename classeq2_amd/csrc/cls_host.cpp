@@ -695,6 +695,13 @@ extern "C" void cls_host_free(void* p) { free(p); }
 extern "C" int cls_place_sequences(cls_db* db, const cls_tree* t, const char* query_path, const char* out_file,
                                    const cls_params* params, int overwrite, int format, uint32_t* n_placed, double* seconds) {
     if (!db || !t || !query_path || !out_file) return fail(CLS_E_INVALID_ARG, "cls_place_sequences: null argument");
+    // released on every way out, a throwing read_file / serialize_pieces included
+    struct Guard {
+        FILE *fo = nullptr, *fe = nullptr;
+        cls_placement* recs = nullptr;
+        cls_fasta fa{};
+        ~Guard() { if (fo) fclose(fo); if (fe) fclose(fe); free(recs); cls_fasta_free(&fa); }
+    } g;
     try {
         // ---- output paths + overwrite policy (mod.rs:73-106) ------------------------------------------
         const std::string out_path = with_extension(out_file, format == CLS_FORMAT_YAML ? "yaml" : "jsonl");
@@ -706,31 +713,35 @@ extern "C" int cls_place_sequences(cls_db* db, const cls_tree* t, const char* qu
             if (!overwrite) return fail(CLS_E_INVALID_ARG, "Could not overwrite existing file \"" + out_path + "\" when overwrite option is `false`.");
             if (unlink(out_path.c_str()) != 0) return fail(CLS_E_INVALID_ARG, std::string("Could not remove file given ") + strerror(errno));
         }
-        FILE* fo = fopen(out_path.c_str(), "ab");  // append mode, created even when nothing is written (write_or_append_to_file.rs:14-21)
-        FILE* fe = fopen(err_path.c_str(), "ab");
-        if (!fo || !fe) { if (fo) fclose(fo); if (fe) fclose(fe); return fail(CLS_E_INVALID_ARG, "Unable to open file"); }
+        FILE*& fo = g.fo;
+        FILE*& fe = g.fe;
+        fo = fopen(out_path.c_str(), "ab");  // append mode, created even when nothing is written (write_or_append_to_file.rs:14-21)
+        fe = fopen(err_path.c_str(), "ab");
+        if (!fo || !fe) return fail(CLS_E_INVALID_ARG, "Unable to open file");
         // ---- read the WHOLE input first (mod.rs:118-119), then place, then write ---------------------------
         auto t0 = std::chrono::steady_clock::now();  // the reference's UCPLACE0001 -> UCPLACE0002 window (mod.rs:64-67, 264-267): read + place + write
         std::string text;
         if (strcmp(query_path, "-") == 0) { std::stringstream ss; ss << std::cin.rdbuf(); text = ss.str(); }
         else text = read_file(query_path);
-        cls_fasta fa;
-        cls_placement* recs = nullptr;  // FASTA stage + placement on the device; headers + records come back
+        cls_fasta& fa = g.fa;
+        cls_placement*& recs = g.recs;  // FASTA stage + placement on the device; headers + records come back
         auto t1 = std::chrono::steady_clock::now();
         int rc = cls_place_fasta_text(db, text.data(), text.size(), params, &fa, &recs);
-        if (rc != CLS_OK) { std::string m = cls_last_error(); fclose(fo); fclose(fe); return fail(rc, m); }
+        if (rc != CLS_OK) { std::string m = cls_last_error(); return fail(rc, m); }
         std::string().swap(text);
         const bool timing = getenv("CLS_TIMING") != nullptr;
         auto t2 = std::chrono::steady_clock::now();
         std::vector<std::string> po, pe;  // the pieces go to the files as they are: no second copy of 300 MB of text
         serialize_pieces(t, fa.headers, fa.header_off, fa.n, recs, format, po, pe);
         free(recs);
+        recs = nullptr;
         auto t3 = std::chrono::steady_clock::now();
         for (auto& x : po) if (!x.empty() && fwrite(x.data(), 1, x.size(), fo) != x.size()) rc = fail(CLS_E_INTERNAL, "Error writing to file");
         for (auto& x : pe) if (!x.empty() && fwrite(x.data(), 1, x.size(), fe) != x.size()) rc = fail(CLS_E_INTERNAL, "Error writing to file");
         if (n_placed) *n_placed = fa.n;
         cls_fasta_free(&fa);
         fclose(fo); fclose(fe);
+        fo = fe = nullptr;
         auto t4 = std::chrono::steady_clock::now();
         if (seconds) *seconds = std::chrono::duration<double>(t4 - t0).count();
         if (timing) {

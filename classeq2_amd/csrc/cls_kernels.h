@@ -2,6 +2,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <string>
+
 #include "cls_device.h"
 
 namespace cls {
@@ -27,6 +29,8 @@ struct PlacePlan {
 // `long_cap`: k-mer capacity wanted for reads beyond MAX_READ_KMERS (0 = refuse them), `n_long`: how many
 // such reads the batch may hold (bounds the number of workspace slices).
 PlacePlan plan_place(const DbDev& db, uint32_t n_reads, uint32_t n_cu, bool stats, uint32_t long_cap, uint32_t n_long);
+// Template instance of the class-0 placement kernel launch_place() picks for `db` (as rocprofv3 names it).
+std::string dominant_kernel_name(const DbDev& db, bool stats);
 // Asynchronous on `stream`; all pointers are device pointers; `d_ws` holds plan.ws_bytes.
 // `ev_start`/`ev_stop` (may be null) are recorded around the class-0 placement kernel.
 hipError_t launch_place(const DbDev& db, const PlaceParams& prm, const PlacePlan& plan, const uint8_t* d_bases,

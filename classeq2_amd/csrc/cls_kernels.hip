@@ -1053,7 +1053,7 @@ __device__ __forceinline__ bool fast_front(const DbDev& db, const FastCtx& cx, c
 template <int SLOTS, int SET_BITS, bool ADDR32>
 __device__ __forceinline__ bool hash_front(const DbDev& db, const FastCtx& cx, const uint8_t* __restrict__ bases, uint64_t b0,
                                            uint32_t L, uint32_t nf, uint32_t nk, uint4 (&ent)[SLOTS], uint32_t (&kw)[SLOTS],
-                                           uint32_t table_bits) {
+                                           uint32_t table_bits, uint32_t& ib) {
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t k = db.k, m_eff = db.m_eff;
     bool bad = false;
@@ -1089,9 +1089,11 @@ __device__ __forceinline__ bool hash_front(const DbDev& db, const FastCtx& cx, c
 #pragma unroll 1
             for (;;) {
                 const uint4 a = ft[2 * idx];
+                ib += 16;
                 if (a.z == 0) break;  // empty slot
                 if ((((uint64_t)a.y << 32) | a.x) == h) {
                     const uint4 b = ft[2 * idx + 1];
+                    ib += 16 + 8;  // second half of the slot + the bucket's key
                     hit = true;
                     st = uint4{a.z, a.w, b.x, b.y};
                     bucket = b.z;
@@ -1126,9 +1128,10 @@ __device__ __forceinline__ bool hash_front(const DbDev& db, const FastCtx& cx, c
 // three 10-bit counters share a word.  (A two-kernel form -- front writes the groups, this runs as its own kernel at 39
 // VGPRs and 8 waves per SIMD -- was measured: 7.4 ms against 6.85 ms fused on C3; more reads in flight do not pay for
 // writing and re-reading 1.6 GB of groups.)
-template <bool PACK10, bool ADDR32, bool POLY>
+// STATS: `ib` accumulates (per lane) the index bytes the descent asks for: 32 per node record, 8 per split half.
+template <bool PACK10, bool ADDR32, bool POLY, bool STATS>
 __device__ __forceinline__ void descend_groups(const DbDev& db, const PlaceParams& prm, const FastCtx& cx, uint32_t n_sets, snode_t P,
-                                               uint32_t r, cls_placement* __restrict__ out) {
+                                               uint32_t r, cls_placement* __restrict__ out, uint32_t& ib) {
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t n_chunks = uniform((n_sets + 63) >> 6);  // wave-uniform; >= 1 here (some k-mer has the root and tips... or none: then 0)
     if (n_sets + lane < 64 * n_chunks) cx.stage[n_sets + lane] = uint4{0xFFFFFFFFu, 0u, 0u, 0u};  // pad the last chunk with inactive entries
@@ -1155,7 +1158,8 @@ __device__ __forceinline__ void descend_groups(const DbDev& db, const PlaceParam
             const DNode* __restrict__ nodes = db.nodes;
             uint32_t last_end = 0;
             if (m) { const snode_t Lc = load_node(nodes, fc + m - 1); last_end = Lc.s[0] + Lc.s[1]; }  // the non-LEAF children come first
-            for (uint32_t i = lane; i < m; i += 64) { cx.ccnt[i] = 0; cx.conly[i] = 0; cx.cpre[i] = nodes[fc + i].pre; }  // children tile [pre+1, last_end)
+            if (STATS && lane == 0 && m) ib += 32;
+            for (uint32_t i = lane; i < m; i += 64) { cx.ccnt[i] = 0; cx.conly[i] = 0; cx.cpre[i] = nodes[fc + i].pre; if (STATS) ib += 4; }  // children tile [pre+1, last_end)
             if (lane == 0) cx.cpre[m] = last_end;
             wave_sync();
             uint32_t u_lane = 0;
@@ -1170,6 +1174,7 @@ __device__ __forceinline__ void descend_groups(const DbDev& db, const PlaceParam
                     if (nin < 2) ++nin;
                     if (vh < c_end) break;                                         // no tip beyond this child
                     const uint2 t = ldx<uint2, ADDR32>(half, 2 * xx + 1);          // first tip beyond it, the split of the rest
+                    if (STATS) ib += 8;
                     v = t.x; xx = t.y;
                 }
                 if (nin == 1) atomicAdd(&cx.conly[which], w);
@@ -1211,6 +1216,7 @@ __device__ __forceinline__ void descend_groups(const DbDev& db, const PlaceParam
             }
             if (n_pass > 1 && n_best != 1) { write_record(out, r, CLS_INCONCLUSIVE, (int32_t)n_pass, 0, (uint32_t)iteration, pid); return; }
             P = load_node(nodes, best_row);
+            if (STATS && lane == 0) ib += 32;
             if (P.s[3] == 0) {
                 write_record(out, r, CLS_IDENTITY_FOUND, best_one, best_rest, (uint32_t)iteration, ((uint64_t)P.s[5] << 32) | P.s[4]);
                 return;
@@ -1222,10 +1228,11 @@ __device__ __forceinline__ void descend_groups(const DbDev& db, const PlaceParam
                 while (!dead && v < c0) {
                     if (vh < c0) { dead = true; break; }
                     const uint2 t = ldx<uint2, ADDR32>(half, 2 * xx + 1);
+                    if (STATS) ib += 8;
                     v = t.x; xx = t.y;
                 }
                 if (!dead && v < c_end && v != c0) {  // a tip strictly below the chosen clade
-                    if (vh >= c_end) { const uint2 t = ldx<uint2, ADDR32>(half, 2 * xx); vh = t.x; xx = t.y; }
+                    if (vh >= c_end) { const uint2 t = ldx<uint2, ADDR32>(half, 2 * xx); vh = t.x; xx = t.y; if (STATS) ib += 8; }
                 } else { v = 0xFFFFFFFFu; vh = 0; }
             };
             enter(vlo, vhi, x);
@@ -1271,6 +1278,7 @@ __device__ __forceinline__ void descend_groups(const DbDev& db, const PlaceParam
         }
         const bool right = only_b > only_a;
         P = load_node(db.nodes, fc + (right ? 1u : 0u));  // (a speculative load of both children was sunk below the tie test by the compiler anyway)
+        if (STATS && lane == 0) ib += 32;
         if (P.s[3] == 0) {  // no non-LEAF child below the chosen clade (update_introspection_node.rs:45-85)
             const uint32_t cn = right ? cnt_b : cnt_a, on = right ? only_b : only_a;
             write_record(out, r, CLS_IDENTITY_FOUND, (int32_t)(rm ? on : cn), (int32_t)(rm ? U - cn : U - on), (uint32_t)iteration,
@@ -1282,6 +1290,7 @@ __device__ __forceinline__ void descend_groups(const DbDev& db, const PlaceParam
         auto narrow = [&](uint32_t& lo_, uint32_t& hi_, uint32_t& x_) {
             const bool str = lo_ < a1 && hi_ >= a1 && (right || lo_ != a0);
             const uint2 t = ldx<uint2, ADDR32>(half, str ? 2 * x_ + (right ? 1u : 0u) : 0u);
+            if (STATS && str) ib += 8;
             if (!right) {
                 const bool gone = lo_ >= a1 || lo_ == a0;  // no tip strictly below the first child
                 if (str) { hi_ = t.x; x_ = t.y; }
@@ -1343,8 +1352,19 @@ __device__ __forceinline__ void place_read_fast(const DbDev& db, const PlacePara
         tb = uniform(tb);
     }
     bool valid_read;
-    if constexpr (HASHED) valid_read = hash_front<LS, SET_BITS, ADDR32>(db, cx, bases, b0, L, nf, nk, ent, kw, tb);
-    else valid_read = fast_front<LS, SET_BITS, ADDR32>(db, cx, bases, b0, L, nf, CANON ? nf : nk, ent, kw, 32, CANON, tb);
+    uint32_t ib = 0;  // STATS: index bytes this lane asked for (table entries, node records, split halves)
+    if constexpr (HASHED) valid_read = hash_front<LS, SET_BITS, ADDR32>(db, cx, bases, b0, L, nf, nk, ent, kw, tb, ib);
+    else {
+        valid_read = fast_front<LS, SET_BITS, ADDR32>(db, cx, bases, b0, L, nf, CANON ? nf : nk, ent, kw, 32, CANON, tb);
+        if (STATS) for (int s = 0; s < LS; ++s) ib += kw[s] ? 16u : 0u;  // one 16-byte table entry per looked-up window
+    }
+    // cls_query_stats.index_bytes: written last, after the counters (put_stats clears the field)
+    auto put_index_bytes = [&]() {
+        if constexpr (STATS) {
+            const uint32_t total = wave_sum(ib);
+            if (stats && lane == 0) reinterpret_cast<uint32_t*>(stats + r)[3] = total;
+        }
+    };
     if (!valid_read) {
         put_stats(0, 0, 0, 0);
         write_record(out, r, CLS_ERR_INVALID_BASE, 0, 0, 0, 0);
@@ -1383,15 +1403,16 @@ __device__ __forceinline__ void place_read_fast(const DbDev& db, const PlacePara
     }
     if (profile_stop == 2) { write_record(out, r, 0xFE, (int32_t)(ent[0].z + ent[LS - 1].w), 0, 0, 0); return; }
     // ---- B. thresholds ------------------------------------------------------------------------------
-    if (n_m == 0) { write_record(out, r, CLS_UNCLASSIFIABLE_NO_MATCH, 0, 0, 0, 0); return; }
-    if (n_root == 0) { write_record(out, r, CLS_UNCLASSIFIABLE_NO_ROOT, 0, 0, 0, 0); return; }
+    if (n_m == 0) { put_index_bytes(); write_record(out, r, CLS_UNCLASSIFIABLE_NO_MATCH, 0, 0, 0, 0); return; }
+    if (n_root == 0) { put_index_bytes(); write_record(out, r, CLS_UNCLASSIFIABLE_NO_ROOT, 0, 0, 0, 0); return; }
     // node records through the scalar unit: a DNode is 8 dwords {pre, size, first_child, n_nonleaf, id lo, id hi, split, flags}
     snode_t P = load_node(db.nodes, 0);
-    if (!(P.s[7] & 1u)) { write_record(out, r, CLS_ERR_ROOT_NO_CHILDREN, 0, 0, 0, 0); return; }
+    if (STATS && lane == 0) ib += 32;
+    if (!(P.s[7] & 1u)) { put_index_bytes(); write_record(out, r, CLS_ERR_ROOT_NO_CHILDREN, 0, 0, 0, 0); return; }
     {
         const double expected = round((double)n_m * prm.min_match_coverage);
         const uint64_t exp_usize = (expected != expected) ? 0ull : (uint64_t)expected;
-        if ((uint64_t)n_root < exp_usize) { write_record(out, r, CLS_UNCLASSIFIABLE_COVERAGE, (int32_t)n_root, 0, 0, 0); return; }
+        if ((uint64_t)n_root < exp_usize) { put_index_bytes(); write_record(out, r, CLS_UNCLASSIFIABLE_COVERAGE, (int32_t)n_root, 0, 0, 0); return; }
     }
     // ---- A4. group the k-mers by tip set ----------------------------------------------------------------
     // k-mers with the same tip list (they share their split tree: same root split, or the same single tip)
@@ -1432,7 +1453,8 @@ __device__ __forceinline__ void place_read_fast(const DbDev& db, const PlacePara
             n_sets += popc64(m);
         }
     }
-    descend_groups<(SLOTS * 64 < 1024), ADDR32, POLY>(db, prm, cx, n_sets, P, r, out);
+    descend_groups<(SLOTS * 64 < 1024), ADDR32, POLY, STATS>(db, prm, cx, n_sets, P, r, out, ib);
+    put_index_bytes();
 }
 
 template <int SLOTS, int SET_BITS, bool STATS, bool ADDR32, int MODE, bool POLY>
@@ -1521,7 +1543,8 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void order_key_kernel(DbDev d
             // both strands files the two under the same leaves, and the key then does not depend on the strand read
             bool valid_read;
             // (without a direct table FWD means "the forward k-mers only": the key then depends on the strand read)
-            if constexpr (HASHED) valid_read = hash_front<LS, 0, ADDR32>(db, cx, bases, b0, L, nf, FWD ? nf : nk, ent, kw, 0);
+            uint32_t ib_unused = 0;
+            if constexpr (HASHED) valid_read = hash_front<LS, 0, ADDR32>(db, cx, bases, b0, L, nf, FWD ? nf : nk, ent, kw, 0, ib_unused);
             else valid_read = fast_front<LS, 0, ADDR32>(db, cx, bases, b0, L, nf, FWD ? nf : nk, ent, kw, sample_shift, FWD);
             if (valid_read) {
                 // candidates: k-mers present in the index that are specific to a small clade (few tips);
@@ -2196,6 +2219,15 @@ size_t blk_smem(const DbDev& db) {
            (child_in_lds(db) ? (size_t)2 * child_ws_stride(db) * 4 : 0);
 }
 }  // namespace
+
+std::string dominant_kernel_name(const DbDev& db, bool stats) {
+    const std::string sl = std::to_string(CLS_SLOTS[0]) + ", " + std::to_string(CLS_SET_BITS[0]) + ", " + (stats ? "true" : "false");
+    auto b = [](bool v) { return std::string(v ? "true" : "false"); };
+    if (use_fast(db))
+        return "place_fast_kernel<" + sl + ", " + b(fast_mode(db) == 2 || db.addr32) + ", " + std::to_string(fast_mode(db)) + ", " + b(!db.binary_tree) + ">";
+    if (db.format == FMT_SPLIT) return "place_split_kernel<" + sl + ", " + b(!db.binary_tree) + ">";
+    return "place_wave_kernel<" + sl + ", " + b(db.max_nonleaf_arity <= 2) + ">";
+}
 
 PlacePlan plan_place(const DbDev& db, uint32_t n_reads, uint32_t n_cu, bool stats, uint32_t long_cap, uint32_t n_long) {
     PlacePlan p{};

@@ -81,7 +81,10 @@ struct cls_service {
             lk.unlock();
             int rc = CLS_OK;
             std::string err;
-            std::vector<cls_placement> out((size_t)reads);
+            std::vector<cls_placement> out;
+            // nothing unwinds out of the worker: an allocation failure fails the group's jobs, not the process
+            try {
+            out.resize((size_t)reads);
             if (!db) { rc = CLS_E_INVALID_ARG; err = "unknown model id " + head->model; }
             else if (reads) {
                 // one concatenated batch: the bases of the jobs back to back, offsets rebased
@@ -99,6 +102,13 @@ struct cls_service {
                 }
                 rc = cls_place_batch(db, bases.data(), off.data(), (uint32_t)reads, head->has_params ? &head->params : nullptr, out.data());
                 if (rc != CLS_OK) err = cls_last_error();
+            }
+            } catch (const std::bad_alloc&) {
+                rc = CLS_E_NOMEM;
+                try { err = "out of host memory while batching the jobs"; } catch (...) {}
+            } catch (...) {
+                rc = CLS_E_INTERNAL;
+                try { err = "unexpected exception in the service worker"; } catch (...) {}
             }
             lk.lock();
             in_flight = false;

@@ -21,7 +21,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libclsplace.so")
 _LIB = None
 
 EXPORTS = [
-    "cls_device_count", "cls_db_create", "cls_db_validate", "cls_db_destroy", "cls_db_info_get", "cls_db_kernel_time",
+    "cls_device_count", "cls_db_create", "cls_db_validate", "cls_db_destroy", "cls_db_info_get", "cls_db_kernel_time", "cls_db_kernel_name",
     "cls_db_set_max_read_len", "cls_place_batch",
     "cls_place_batch_device", "cls_place_batch_stats", "cls_fasta_parse", "cls_fasta_free", "cls_fasta_scan_device", "cls_fasta_dev_free",
     "cls_fasta_parse_gpu", "cls_place_fasta_text", "cls_last_error",
@@ -67,6 +67,8 @@ def lib():
         L.cls_db_info_get.restype = i32
         L.cls_db_kernel_time.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_uint64), i32]
         L.cls_db_kernel_time.restype = i32
+        L.cls_db_kernel_name.argtypes = [vp, C.c_char_p, C.c_size_t]
+        L.cls_db_kernel_name.restype = i32
         L.cls_db_set_max_read_len.argtypes = [vp, C.c_uint64]
         L.cls_db_set_max_read_len.restype = i32
         L.cls_place_batch.argtypes = [vp, vp, vp, u32, C.POINTER(_abi.Params), vp]
@@ -212,13 +214,27 @@ class PlacementDb:
     def __exit__(self, *a):
         self.close()
 
+    def refresh_info(self):
+        """Re-read cls_db_info (scratch_slots and max_read_kmers change over a handle's life)."""
+        _check(lib().cls_db_info_get(self._h, C.byref(self.info)))
+        return self.info
+
+    def kernel_name(self) -> str:
+        """Template instance of the dominant placement kernel this handle launches (cls_db_kernel_name)."""
+        buf = C.create_string_buffer(256)
+        _check(lib().cls_db_kernel_name(self._h, buf, len(buf)))
+        return buf.value.decode()
+
     def place_batch(self, bases: np.ndarray, offsets: np.ndarray, params: Optional[_abi.Params] = None,
-                    want_stats: bool = False):
-        """Host buffers in, host records out (cls_place_batch / cls_place_batch_stats)."""
+                    want_stats: bool = False, out: Optional[np.ndarray] = None):
+        """Host buffers in, host records out (cls_place_batch / cls_place_batch_stats).  `out`: caller-owned record
+        array (e.g. in pinned memory) to fill instead of a fresh one."""
         bases = np.ascontiguousarray(bases, dtype=np.uint8)
         offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
         n = len(offsets) - 1
-        out = np.zeros(n, dtype=_abi.PLACEMENT_DTYPE)
+        if out is None:
+            out = np.zeros(n, dtype=_abi.PLACEMENT_DTYPE)
+        assert out.dtype == _abi.PLACEMENT_DTYPE and len(out) >= n and out.flags.c_contiguous
         pp = C.byref(params) if params is not None else None
         if want_stats:
             stats = np.zeros(n, dtype=_abi.STATS_DTYPE)

@@ -53,7 +53,14 @@ CONFIGS = {
     "C2": dict(n_leaves=1000, ref_len=1500, k_size=8, m_size=4, n_reads=100_000, read_len=150, deep=0, max_depth=0),
     "C3": dict(n_leaves=10_000, ref_len=1500, k_size=12, m_size=4, n_reads=1_000_000, read_len=150, deep=0, max_depth=0),
     "C4": dict(n_leaves=10_000, ref_len=1500, k_size=12, m_size=4, n_reads=10_000_000, read_len=150, deep=0, max_depth=0),
-    "C5": dict(n_leaves=50_000, ref_len=12_000, k_size=15, m_size=4, n_reads=1_000_000, read_len=10_000, deep=1, max_depth=900),
+    "C5": dict(n_leaves=50_000, ref_len=12_000, k_size=15, m_size=4, n_reads=1_000_000, read_len=10_000, deep=1, max_depth=900,
+               tips_only=True),
+    # the shapes the reference actually ships: `cls build-db -s 70` collapses low-support branches into polytomies
+    # (tree.rs:248-285), and its default is k=35, m=4 (docs/book/02-build-db.md:109-129)
+    "C3s12": dict(n_leaves=10_000, ref_len=1500, k_size=12, m_size=4, n_reads=1_000_000, read_len=150, deep=0, max_depth=0,
+                  collapse_prob=0.3),
+    "C3s35": dict(n_leaves=10_000, ref_len=1500, k_size=35, m_size=4, n_reads=1_000_000, read_len=150, deep=0, max_depth=0,
+                  collapse_prob=0.3),
 }
 
 

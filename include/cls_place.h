@@ -148,7 +148,9 @@ typedef struct cls_query_stats {
     uint32_t n_query_kmers;    /* query.kmers.count       = 2(L-k+1)             */
     uint32_t n_matched;        /* query.kmers.treeMatches = |M|                  */
     uint32_t n_with_root;      /* subject.kmers.queryMatches = |M_root|          */
-    uint32_t pad_;
+    uint32_t index_bytes;      /* engine-side accounting, not a reference quantity: bytes of index data (table
+                                * entries, node records, split records) the kernels asked for to place this read;
+                                * bench.py's roofline numerator; 0 where a kernel does not count it */
     uint64_t leaf_postings;    /* sum over M of |{LEAF-kind ids in nodes(h)}|    */
 } cls_query_stats;             /* 24 bytes */
 
@@ -173,6 +175,9 @@ typedef struct cls_db_info {
     uint32_t direct_table;     /* 1: 2-bit-code direct table in use (k <= 15); 2: and the index is strand-symmetric
                                 * (every k-mer shares its node set with its reverse complement: one lookup per window) */
     uint32_t n_tip_sets;       /* format 1: distinct tip lists (k-mers with the same one share a split tree) */
+    uint32_t scratch_slots;    /* per-call scratch workspaces the handle holds right now (a caller that pipelines
+                                * batches on ONE stream keeps one; at most 8) */
+    uint32_t pad_;
 } cls_db_info;
 
 /* Number of usable HIP devices (0 if none). */
@@ -204,9 +209,10 @@ int cls_place_batch(cls_db* db, const char* bases, const uint64_t* offsets, uint
 int cls_place_batch_device(cls_db* db, const void* d_bases, const void* d_offsets, uint32_t n,
                            const cls_params* params, void* d_out, void* d_stats, void* hip_stream);
 
-/* Longest read (bases) cls_place_batch_device() provisions scratch for (default 16384; the lengths of a
- * device-resident batch are not known to the host).  Reads with more than 8192 k-mers keep their per-k-mer
- * state in the workspace: 80 bytes per base and resident workgroup.  At most 2^25. */
+/* Longest read (bases) cls_place_batch_device() provisions scratch for (the lengths of a device-resident batch
+ * are not known to the host).  Default 0: reads of up to 8192 k-mers (4096 + k - 1 bases) only, longer ones are
+ * reported CLS_ERR_READ_TOO_LONG; a caller with longer reads opts in here.  Reads with more than 8192 k-mers keep
+ * their per-k-mer state in the workspace: 80 bytes per base and resident workgroup.  At most 2^25. */
 int cls_db_set_max_read_len(cls_db* db, uint64_t n_bases);
 
 /* Device time of the DOMINANT placement kernel (the per-read placement kernel of the
@@ -215,6 +221,9 @@ int cls_db_set_max_read_len(cls_db* db, uint64_t n_bases);
  * caller's stream.  Waits for the launches still in flight.  Measurement aid for
  * bench.py's roofline figure; `reset` != 0 clears the accumulators afterwards. */
 int cls_db_kernel_time(cls_db* db, double* sum_ms, uint64_t* launches, int reset);
+/* Name (template instance, as rocprofv3 prints it without the argument list) of that dominant kernel for this
+ * handle, without statistics: lets bench.py tie a committed profile to the kernel it really launches. */
+int cls_db_kernel_name(const cls_db* db, char* buf, size_t len);
 
 /* Host-buffer variant that also returns the per-query counters. */
 int cls_place_batch_stats(cls_db* db, const char* bases, const uint64_t* offsets, uint32_t n,

@@ -38,6 +38,22 @@ def stats_equal(a: np.ndarray, b: np.ndarray):
     return np.nonzero(bad)[0]
 
 
+def device_place(db, bases, offsets, params=None, want_stats=True):
+    """cls_place_batch_device on torch-owned HBM buffers (cuda:0) -> (records, stats)."""
+    import torch
+
+    dev = torch.device("cuda:0")
+    n = len(offsets) - 1
+    d_b = torch.from_numpy(bases if len(bases) else np.zeros(1, np.uint8)).to(dev)
+    d_o = torch.from_numpy(offsets.astype(np.int64)).to(dev)
+    d_out = torch.zeros(n * 24, dtype=torch.uint8, device=dev)
+    d_st = torch.zeros(n * 24, dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
+    db.place_batch_device(d_b.data_ptr(), d_o.data_ptr(), n, d_out.data_ptr(), params, d_st.data_ptr() if want_stats else 0, 0)
+    torch.cuda.synchronize()
+    return d_out.cpu().numpy().view(_abi.PLACEMENT_DTYPE), d_st.cpu().numpy().view(_abi.STATS_DTYPE)
+
+
 def describe(rec) -> str:
     return f"{_abi.STATUS_NAMES[int(rec['status'])]} one={rec['one']} rest={rec['rest']} levels={rec['levels']} clade={rec['clade_id']}"
 

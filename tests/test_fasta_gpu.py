@@ -1,11 +1,13 @@
-"""FASTA stage on the device against the host parser (which tests/test_host_cpu.py holds to the
-literal oracle): identical records, bases, offsets and truncation flag, on the fixed corner cases, on random
-texts built from the characters that matter, and on a file-sized input placed end to end."""
+"""FASTA stage on the device against the literal oracle (`oracle_literal.sequence_content_by_channel`,
+file_or_stdin.rs:76-116) directly, and against the host parser: identical records, bases, offsets and truncation
+flag, on the fixed corner cases, on random texts built from the characters that matter, and on a file-sized input
+placed end to end."""
 import numpy as np
 import pytest
 
 from classeq2_amd import _abi, engine
 from classeq2_amd.synth import SynthDb
+from oracle import oracle_literal as lit
 from oracle import oracle_port as op
 from tests.helpers import records_equal
 from tests.test_host_cpu import FASTA_CASES
@@ -19,6 +21,17 @@ def _same(txt: bytes):
     assert got[0] == want[0], (txt[:80], got[0][:3], want[0][:3])
     assert np.array_equal(got[2], want[2]) and np.array_equal(got[1], want[1])
     assert got[3] == want[3]
+    # ... and the device stage against the literal oracle itself (no transitive step through the host parser)
+    headers, bases, off, truncated = got
+    recs = [(headers[i].decode("utf-8"), bytes(bases[int(off[i]):int(off[i + 1])]).decode()) for i in range(len(headers))]
+    try:
+        text = txt.decode("utf-8")
+    except UnicodeDecodeError as e:  # BufRead::lines() stops at the first line that is not UTF-8
+        cut = txt.rfind(b"\n", 0, e.start) + 1
+        lit_recs = lit.sequence_content_by_channel(txt[:cut].decode("utf-8"))
+        assert recs == lit_recs[: len(recs)] and truncated  # records completed before the bad line were sent; the pending one is lost
+        return want
+    assert recs == lit.sequence_content_by_channel(text), txt[:80]
     return want
 
 

@@ -1,0 +1,101 @@
+"""The HEADLINE index under parity: BASELINE config C3 (10 000 leaves, k=12, seeds tree=1 / refseq=2) is built at
+full size and `cls_place_batch_device` -- the entry bench.py times, on the bench's own read stream (seed 3), batch
+large enough for the locality-ordered path -- is compared with the C oracle, records AND counters, for both values of
+remove_intersection.  C3-only state this exercises: 459 k shared tip sets, the strand-symmetric direct table over
+4^12 codes, sort keys sized by 3.2 M k-mers, the XCD-sliced walk.  Reference path: place_sequence.rs:279-601."""
+import numpy as np
+import pytest
+
+from classeq2_amd import _abi, engine
+from classeq2_amd.synth import CONFIGS, SynthDb
+from oracle import oracle_port as op
+from tests.helpers import describe, device_place, records_equal, stats_equal
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def c3():
+    cfg = CONFIGS["C3"]
+    s = SynthDb(cfg["n_leaves"], cfg["ref_len"], cfg["k_size"], cfg["m_size"])
+    oracle = op.OraclePort(s.flat)
+    db = engine.PlacementDb(s.flat, device=0)
+    yield s, oracle, db
+    db.close()
+    oracle.close()
+
+
+def _compare(got, gst, want, wst, what):
+    bad = records_equal(got, want)
+    assert len(bad) == 0, f"{what}: {len(bad)} records differ, first {bad[0]}: got {describe(got[bad[0]])} want {describe(want[bad[0]])}"
+    sb = stats_equal(gst, wst)
+    assert len(sb) == 0, f"{what}: {len(sb)} stats differ, first {sb[0]}: got {gst[sb[0]]} want {wst[sb[0]]}"
+
+
+def test_c3_index_is_the_headline_layout(c3):
+    s, _, db = c3
+    assert db.info.n_nodes == 19999 and db.info.k_size == 12
+    assert (db.info.format, db.info.binary_tree, db.info.direct_table) == (1, 1, 2)
+    assert db.info.n_kmers > 3_000_000 and 400_000 < db.info.n_tip_sets < 500_000
+
+
+@pytest.mark.parametrize("first,n", [(0, 100_000), (900_000, 30_000)])
+def test_c3_bench_stream_against_the_oracle(c3, first, n):
+    """>= 100 k reads of the bench's stream (its first reads, and a slice near its end)."""
+    s, oracle, db = c3
+    bases, offsets, _ = s.reads(n, 150, seed=3, first=first)
+    wants = []
+    for kw in (dict(), dict(remove_intersection=True)):
+        got, gst = device_place(db, bases, offsets, engine.make_params(**kw))
+        want, wst = oracle.place_batch(bases, offsets, op.make_params(**kw), threads=16, want_stats=True)
+        _compare(got, gst, want, wst, f"first={first} {kw}")
+        assert (gst["index_bytes"] > 0).all()  # the fast path accounts the index bytes it asks for (bench.py's roofline)
+        wants.append(want)
+    # the same reads through the host-buffer entry (cls_place_batch: pipelined H2D / D2H), all-None parameters
+    host = db.place_batch(bases, offsets)
+    bad = records_equal(host, wants[0])
+    assert len(bad) == 0, f"host entry: {len(bad)} records differ from the oracle"
+    assert np.bincount(host["status"], minlength=12)[_abi.IDENTITY_FOUND] > 0.9 * n
+
+
+def test_c3_small_batches_take_the_unordered_path(c3):
+    """< 4096 reads: no locality order, plain class lists."""
+    s, oracle, db = c3
+    bases, offsets, _ = s.reads(3000, 150, seed=3, first=500_000)
+    got, gst = device_place(db, bases, offsets, None)
+    want, wst = oracle.place_batch(bases, offsets, threads=16, want_stats=True)
+    _compare(got, gst, want, wst, "3000 reads")
+
+
+def test_async_calls_on_one_stream_share_one_scratch_slot(c3):
+    """A caller that pipelines many batches on ONE stream without synchronising keeps a single scratch workspace
+    (the next launch is stream-ordered behind the previous one); records stay those of a synchronous call."""
+    import torch
+
+    s, _, db = c3
+    n = 50_000
+    bases, offsets, _ = s.reads(n, 150, seed=3, first=200_000)
+    dev = torch.device("cuda:0")
+    d_b = torch.from_numpy(bases).to(dev)
+    d_o = torch.from_numpy(offsets.astype(np.int64)).to(dev)
+    outs = [torch.zeros(n * 24, dtype=torch.uint8, device=dev) for _ in range(12)]
+    torch.cuda.synchronize()
+    before = db.refresh_info().scratch_slots
+    st = torch.cuda.current_stream().cuda_stream
+    for o in outs:
+        db.place_batch_device(d_b.data_ptr(), d_o.data_ptr(), n, o.data_ptr(), None, 0, st)
+    slots = db.refresh_info().scratch_slots
+    torch.cuda.synchronize()
+    assert slots <= max(1, before), f"{slots} scratch slots for one stream (had {before})"
+    ref = outs[0].cpu().numpy().view(_abi.PLACEMENT_DTYPE)
+    for o in outs[1:]:
+        assert len(records_equal(o.cpu().numpy().view(_abi.PLACEMENT_DTYPE), ref)) == 0
+    # two streams in flight at once need two slots, and the pool stays bounded
+    s2 = torch.cuda.Stream()
+    for i in range(6):
+        db.place_batch_device(d_b.data_ptr(), d_o.data_ptr(), n, outs[2 * i].data_ptr(), None, 0, st)
+        db.place_batch_device(d_b.data_ptr(), d_o.data_ptr(), n, outs[2 * i + 1].data_ptr(), None, 0, s2.cuda_stream)
+    torch.cuda.synchronize()
+    assert db.refresh_info().scratch_slots <= 8
+    for o in outs:
+        assert len(records_equal(o.cpu().numpy().view(_abi.PLACEMENT_DTYPE), ref)) == 0

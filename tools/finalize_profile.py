@@ -1,5 +1,7 @@
-"""Copy one tools/profile.sh run (gpurun_out/<tag>/ + gpurun_out/<tag>_bench_full.json) into profiles/ as
-<tag>_{pmc,kernel_stats,bench}_C3 and point profiles/traffic.json at it.  usage: finalize_profile.py <tag> [old_tag_to_remove]"""
+"""Copy one tools/profile.sh run (gpurun_out/<tag>/) into profiles/ as <tag>_{pmc,kernel_stats,bench}_<config> and
+point profiles/traffic.json at it, stamped with the source fingerprint and the kernel instance the counters were
+taken from (bench.py reports `traffic: null, traffic_stale: true` for anything else).
+usage: finalize_profile.py <tag> [old_tag_to_remove]"""
 import json
 import os
 import shutil
@@ -7,25 +9,39 @@ import sys
 
 tag = sys.argv[1]
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, root)
 src = os.path.join(root, "gpurun_out", tag)
 d = json.load(open(os.path.join(src, "pmc_summary.json")))
-d["workload"] = "C3: 10k-leaf tree, 1M x 150 bp reads, k=12, 1x MI355X"
+cfg = d.get("config", "C3")
+b = json.loads([l for l in open(os.path.join(src, "bench.json")) if l.startswith("{")][-1])
+d["workload"] = b["config"]["workload"]
 d["note"] = ("FETCH_SIZE*1024 == TCC_MISS_sum*64 B here (narrow random reads: one 64-byte request per L2 miss), so the x2 "
              "streaming correction of MI355X_MICROARCH.md does not apply to this access pattern")
 d["kernels"] = {(k if len(k) < 80 else k[:77] + "..."): v for k, v in d["kernels"].items()}
 prof = os.path.join(root, "profiles")
-json.dump(d, open(os.path.join(prof, f"{tag}_pmc_C3.json"), "w"), indent=1)
+json.dump(d, open(os.path.join(prof, f"{tag}_pmc_{cfg}.json"), "w"), indent=1)
 traffic = d["dominant_kernel_hbm_bytes_per_launch"]
-json.dump({"C3:1000000": {"hbm_bytes_per_launch": traffic, "source": f"profiles/{tag}_pmc_C3.json", "kernel": d["dominant_kernel"]}},
-          open(os.path.join(prof, "traffic.json"), "w"), indent=1)
-shutil.copy(os.path.join(src, "kernel_stats.csv"), os.path.join(prof, f"{tag}_kernel_stats_C3.csv"))
-b = json.load(open(os.path.join(root, "gpurun_out", f"{tag}_bench_full.json")))
-b["roofline"]["traffic"] = traffic  # (the line was printed with the previous traffic.json)
-b["roofline"]["traffic_frac"] = traffic / (b["roofline"]["kernel_ms"] * 1e-3) / 1e9 / 8000.0
-json.dump(b, open(os.path.join(prof, f"{tag}_bench_C3.json"), "w"))
+tpath = os.path.join(prof, "traffic.json")
+try:
+    table = json.load(open(tpath))
+except (OSError, ValueError):
+    table = {}
+reads = b["config"]["reads_per_gpu"]
+table[f"{cfg}:{reads}"] = {"hbm_bytes_per_launch": traffic, "source": f"profiles/{tag}_pmc_{cfg}.json", "kernel": d["dominant_kernel"],
+                           "source_sha16": d["source_sha16"]}
+json.dump(table, open(tpath, "w"), indent=1)
+shutil.copy(os.path.join(src, "kernel_stats.csv"), os.path.join(prof, f"{tag}_kernel_stats_{cfg}.csv"))
+r = b["roofline"]
+r["traffic"] = traffic  # (the line was printed before this profile was folded into traffic.json)
+r["traffic_stale"] = False
+ksec = r["kernel_ms"] * 1e-3
+r["traffic_frac"] = traffic / ksec / 1e9 / 8000.0
+if r.get("needed_bytes_per_launch"):
+    r["overfetch"] = traffic / r["needed_bytes_per_launch"]
+json.dump(b, open(os.path.join(prof, f"{tag}_bench_{cfg}.json"), "w"))
 if len(sys.argv) > 2:
-    for suffix in ("pmc_C3.json", "kernel_stats_C3.csv", "bench_C3.json"):
+    for suffix in (f"pmc_{cfg}.json", f"kernel_stats_{cfg}.csv", f"bench_{cfg}.json"):
         f = os.path.join(prof, f"{sys.argv[2]}_{suffix}")
         if os.path.exists(f):
             os.remove(f)
-print(tag, b["value"], b["ms_per_step"], b["roofline"])
+print(tag, cfg, b["value"], b["ms_per_step"], json.dumps(r))
