@@ -177,6 +177,7 @@ def main():
     from classeq2_amd import _abi, engine
     from classeq2_amd.synth import CONFIGS, SynthDb
 
+    engine.tuning_from_env()  # CLS_* experiment knobs for A/B runs (none changes a result; the library never reads them itself)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

@@ -2,7 +2,8 @@
 
 import ctypes as C
 
-ABI_VERSION = 1
+ABI_VERSION = 2
+SETS_EXPLICIT, SETS_LEAVES = 0, 1
 
 KIND_ROOT, KIND_NODE, KIND_LEAF = 0, 1, 2
 NO_PARENT = (1 << 64) - 1
@@ -68,6 +69,8 @@ class DbDesc(C.Structure):
         ("kmer_hash", C.POINTER(C.c_uint64)),
         ("kmer_node_off", C.POINTER(C.c_uint64)),
         ("node_ids", C.POINTER(C.c_uint64)),
+        ("node_set_kind", C.c_uint32),
+        ("pad_", C.c_uint32),
     ]
 
 
@@ -163,7 +166,7 @@ class SynthCfg(C.Structure):
         ("id_stride", C.c_uint64),
         ("id_offset", C.c_uint64),
         ("threads", C.c_uint32),
-        ("pad_", C.c_uint32),
+        ("tips_only", C.c_uint32),
     ]
 
 

@@ -2,7 +2,9 @@
 // the host-buffer and device-buffer batch entry points.  Nothing unwinds across
 // the boundary; every failure leaves a thread-local message for cls_last_error().
 #include <hip/hip_runtime.h>
+#include <ctype.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -16,6 +18,7 @@
 #include "cls_device.h"
 #include "cls_kernels.h"
 #include "cls_place.h"
+#include "cls_tuning.h"
 
 namespace {
 
@@ -88,7 +91,7 @@ struct cls_db {
     void* d_postings = nullptr;
     void* d_bucket_key = nullptr;
     void* d_direct = nullptr;
-    void* d_ftable = nullptr;
+    void* d_sets = nullptr;
     std::mutex ws_mu;
     uint64_t max_read_len = 0;  // what the device-buffer entry provisions its long-read slices for (0: none, reads of up to
                                 // MAX_READ_KMERS k-mers only; cls_db_set_max_read_len opts in)
@@ -99,6 +102,40 @@ struct cls_db {
     uint64_t ws_seq = 0;
     std::vector<CallSlot> calls;  // host-buffer calls: stream + staging buffers (ws_mu)
 };
+
+// ---- experiment knobs (csrc/cls_tuning.h) ------------------------------------------------------------------
+namespace cls {
+Tuning& tuning() {
+    static Tuning t;
+    return t;
+}
+}  // namespace cls
+namespace {
+struct Knob { const char* name; int cls::Tuning::*field; };
+const Knob KNOBS[] = {
+    {"no_fast", &cls::Tuning::no_fast}, {"no_order", &cls::Tuning::no_order}, {"force_list", &cls::Tuning::force_list},
+    {"no_tile", &cls::Tuning::no_tile}, {"tile_pass_codes", &cls::Tuning::tile_pass_codes}, {"blocks_per_cu", &cls::Tuning::blocks_per_cu}, {"key_blocks_per_cu", &cls::Tuning::key_blocks_per_cu},
+    {"long_blocks_per_cu", &cls::Tuning::long_blocks_per_cu}, {"order_mode", &cls::Tuning::order_mode},
+    {"order_windows", &cls::Tuning::order_windows}, {"order_both_strands", &cls::Tuning::order_both_strands},
+    {"order_block_shift", &cls::Tuning::order_block_shift}, {"order_sample_shift", &cls::Tuning::order_sample_shift},
+    {"profile_stop", &cls::Tuning::profile_stop}, {"timing", &cls::Tuning::timing},
+};
+}  // namespace
+
+extern "C" int cls_set_tuning(const char* name, int value) {
+    if (!name) return fail(CLS_E_INVALID_ARG, "cls_set_tuning: null name");
+    for (const Knob& k : KNOBS)
+        if (strcmp(k.name, name) == 0) { cls::tuning().*(k.field) = value; return CLS_OK; }
+    return fail(CLS_E_INVALID_ARG, std::string("cls_set_tuning: unknown knob ") + name);
+}
+
+extern "C" void cls_tuning_from_env(void) {
+    for (const Knob& k : KNOBS) {
+        std::string var = "CLS_";
+        for (const char* c = k.name; *c; ++c) var += (char)toupper((unsigned char)*c);
+        if (const char* v = getenv(var.c_str())) cls::tuning().*(k.field) = *v ? atoi(v) : 1;  // (an empty value means "on")
+    }
+}
 
 extern "C" const char* cls_last_error(void) { return g_err.c_str(); }
 extern "C" void cls_internal_set_error(const char* msg) { g_err = msg ? msg : ""; }  // for the library's other translation units
@@ -133,7 +170,7 @@ extern "C" void cls_db_destroy(cls_db* db) {
     if (db->d_postings) (void)hipFree(db->d_postings);
     if (db->d_bucket_key) (void)hipFree(db->d_bucket_key);
     if (db->d_direct) (void)hipFree(db->d_direct);
-    if (db->d_ftable) (void)hipFree(db->d_ftable);
+    if (db->d_sets) (void)hipFree(db->d_sets);
     if (have_prev) (void)hipSetDevice(prev);
     delete db;
 }
@@ -146,7 +183,7 @@ extern "C" int cls_db_create(const cls_db_desc* d, int device, cls_db** out) {
         std::string err;
         int rc = cls::encode_db(d, E, err);
         if (rc != CLS_OK) return fail(rc, "cls_db_create: " + err);
-        if (E.postings.size() >= (1ULL << 32)) return fail(CLS_E_BAD_DB, "cls_db_create: postings exceed 2^32 words");
+        if (E.format == cls::FMT_LIST && E.postings.size() >= (1ULL << 32)) return fail(CLS_E_BAD_DB, "cls_db_create: sorted-list postings exceed 2^32 words");
         int n_dev = 0;
         if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev == 0)
             return fail(CLS_E_NO_DEVICE, "cls_db_create: no HIP device is visible (the placement path has no CPU fallback)");
@@ -169,7 +206,7 @@ extern "C" int cls_db_create(const cls_db_desc* d, int device, cls_db** out) {
             (e = up(&db->d_postings, E.postings.data(), E.postings.size() * 4)) != hipSuccess ||
             (e = up(&db->d_bucket_key, E.bucket_key.data(), E.bucket_key.size() * 8)) != hipSuccess ||
             (!E.direct.empty() && (e = up(&db->d_direct, E.direct.data(), E.direct.size() * 4)) != hipSuccess) ||
-            (!E.ftable.empty() && (e = up(&db->d_ftable, E.ftable.data(), E.ftable.size() * sizeof(cls::FSlot))) != hipSuccess)) {
+            (!E.sets.empty() && (e = up(&db->d_sets, E.sets.data(), E.sets.size() * sizeof(cls::SetRec))) != hipSuccess)) {
             cls_db_destroy(db);
             return fail(e == hipErrorOutOfMemory ? CLS_E_NOMEM : CLS_E_HIP, std::string("cls_db_create: upload failed: ") + hipGetErrorString(e));
         }
@@ -179,7 +216,7 @@ extern "C" int cls_db_create(const cls_db_desc* d, int device, cls_db** out) {
         v.postings = (const uint32_t*)db->d_postings;
         v.bucket_key = (const uint64_t*)db->d_bucket_key;
         v.direct = (const uint32_t*)db->d_direct;
-        v.ftable = (const cls::FSlot*)db->d_ftable;
+        v.sets = (const cls::SetRec*)db->d_sets;
         v.table_mask = E.table.size() - 1;
         v.n_nodes = (uint32_t)E.nodes.size();
         v.n_buckets = (uint32_t)E.bucket_key.size();
@@ -189,9 +226,10 @@ extern "C" int cls_db_create(const cls_db_desc* d, int device, cls_db** out) {
         v.format = E.format;
         v.binary_tree = E.strictly_binary ? 1u : 0u;
         v.canonical = E.canonical ? 1u : 0u;
-        v.hdr_bits = 1;
-        while (v.hdr_bits < 32 && (1ull << v.hdr_bits) <= (uint64_t)cls::SPLIT_FIRST_REC + cls::SPLIT_HEADER_RECS * E.n_kmers) ++v.hdr_bits;
-        v.addr32 = (E.postings.size() * 4 < (1ull << 32) && E.direct.size() * 4 < (1ull << 32)) ? 1u : 0u;
+        v.n_sets = (uint32_t)E.sets.size();
+        v.set_bits = 1;
+        while (v.set_bits < 32 && (1ull << v.set_bits) < (uint64_t)E.sets.size()) ++v.set_bits;
+        v.addr32 = (E.postings.size() * 4 < (1ull << 32) && E.direct.size() * 4 < (1ull << 32) && E.sets.size() * sizeof(cls::SetRec) < (1ull << 32)) ? 1u : 0u;
         cls_db_info& i = db->info;
         i.n_nodes = v.n_nodes;
         i.max_depth = E.max_depth;
@@ -203,7 +241,7 @@ extern "C" int cls_db_create(const cls_db_desc* d, int device, cls_db** out) {
         i.n_closed_kmers = E.n_closed;
         i.table_slots = E.table.size();
         i.postings_words = E.postings.size();
-        i.hbm_bytes = E.nodes.size() * sizeof(cls::DNode) + E.table.size() * sizeof(cls::Slot) + E.postings.size() * 4 + E.bucket_key.size() * 8 + E.direct.size() * 4 + E.ftable.size() * sizeof(cls::FSlot);
+        i.hbm_bytes = E.nodes.size() * sizeof(cls::DNode) + E.table.size() * sizeof(cls::Slot) + E.postings.size() * 4 + E.bucket_key.size() * 8 + E.direct.size() * 4 + E.sets.size() * sizeof(cls::SetRec);
         i.max_read_kmers = (uint32_t)std::max<uint64_t>(cls::MAX_READ_KMERS, 2 * db->max_read_len);
         i.device = device;
         i.format = E.format;
@@ -227,7 +265,6 @@ extern "C" int cls_db_validate(const cls_db_desc* d) {
         std::string err;
         int rc = cls::encode_db(d, E, err);
         if (rc != CLS_OK) return fail(rc, "cls_db_validate: " + err);
-        if (E.postings.size() >= (1ULL << 32)) return fail(CLS_E_BAD_DB, "cls_db_validate: postings exceed 2^32 words");
         return CLS_OK;
     } catch (const std::bad_alloc&) {
         return fail(CLS_E_NOMEM, "cls_db_validate: out of host memory");

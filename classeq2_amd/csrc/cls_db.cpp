@@ -4,12 +4,15 @@
 #include "cls_db.h"
 
 #include "cls_murmur.h"
+#include "cls_tuning.h"
 
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <exception>
 #include <functional>
 #include <mutex>
@@ -72,7 +75,8 @@ void parallel_sort(std::vector<T>& v, unsigned n_threads, Cmp cmp) {
 int encode_db(const cls_db_desc* d, EncodedDb& E, std::string& err) {
     // ---- 0. argument checks ---------------------------------------------------
     if (!d) { err = "null descriptor"; return CLS_E_INVALID_ARG; }
-    if (d->abi_version != CLS_ABI_VERSION) { err = "cls_db_desc.abi_version mismatch"; return CLS_E_INVALID_ARG; }
+    if (d->abi_version != 1 && d->abi_version != CLS_ABI_VERSION) { err = "cls_db_desc.abi_version mismatch"; return CLS_E_INVALID_ARG; }
+    if (d->abi_version >= 2 && d->node_set_kind > CLS_SETS_LEAVES) { err = "cls_db_desc.node_set_kind out of range"; return CLS_E_INVALID_ARG; }
     if (d->n_nodes == 0 || !d->nodes) { err = "empty node table"; return CLS_E_BAD_TREE; }
     if (d->k_size == 0 || d->k_size > MAX_K) { err = "kSize must be in [1, " + std::to_string(MAX_K) + "]"; return CLS_E_BAD_DB; }
     if (d->n_buckets >= (1ULL << LOC_BUCKET_BITS)) { err = "too many minimizer buckets (>= 2^24)"; return CLS_E_BAD_DB; }
@@ -89,6 +93,14 @@ int encode_db(const cls_db_desc* d, EncodedDb& E, std::string& err) {
     if (d->n_kmers && d->kmer_node_off[d->n_kmers] && !d->node_ids) { err = "null node_ids"; return CLS_E_INVALID_ARG; }
 
     const uint32_t N = d->n_nodes;
+    // phase times on stderr when the `timing` knob is set (cls_set_tuning): index builds at BASELINE config 5's size take minutes
+    auto t_last = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) {
+        if (!tuning().timing) return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "encode_db: %-28s %8.2f s\n", what, std::chrono::duration<double>(now - t_last).count());
+        t_last = now;
+    };
     // ---- 1. validate the row table is a tree rooted at row 0 -------------------
     std::vector<uint32_t> order;  // engine row -> caller row (BFS, non-LEAF children first)
     order.reserve(N);
@@ -176,16 +188,29 @@ int encode_db(const cls_db_desc* d, EncodedDb& E, std::string& err) {
         auto it = std::lower_bound(id2pre.begin(), id2pre.end(), std::make_pair(id, (uint32_t)0));
         return (it != id2pre.end() && it->first == id) ? it->second : UINT32_MAX;
     };
+    lap("tree");
     // ---- 4. per k-mer: node set -> sorted pre list -> tips / explicit list -------
     const uint64_t NK = d->n_kmers;
+    const bool leaves_only = d->abi_version >= 2 && d->node_set_kind == CLS_SETS_LEAVES;
+    if (leaves_only) {
+        // the ids name LEAF-kind clades; the node set is the union of their root->leaf paths (build_database/mod.rs:160-169).
+        // A LEAF-kind clade with children could sit ON such a path without being listed: keep the contract simple.
+        for (uint32_t r = 0; r < N; ++r)
+            if (d->nodes[order[r]].kind == CLS_KIND_LEAF && d->nodes[order[r]].n_children) {
+                err = "leaves-only node sets need childless LEAF clades"; return CLS_E_BAD_DB;
+            }
+    }
+    unsigned nt = std::max(1u, std::min(64u, std::thread::hardware_concurrency()));
     std::vector<uint32_t> bucket_of(NK);
-    for (uint64_t b = 0; b < d->n_buckets; ++b)
-        for (uint64_t j = d->bucket_kmer_off[b]; j < d->bucket_kmer_off[b + 1]; ++j) bucket_of[j] = (uint32_t)b;
-    unsigned nt = std::max(1u, std::min(32u, std::thread::hardware_concurrency()));
+    parallel_chunks(d->n_buckets, nt, [&](unsigned, uint64_t lo, uint64_t hi) {
+        for (uint64_t b = lo; b < hi; ++b)
+            for (uint64_t j = d->bucket_kmer_off[b]; j < d->bucket_kmer_off[b + 1]; ++j) bucket_of[j] = (uint32_t)b;
+    });
     std::vector<std::vector<uint32_t>> chunk_words(nt);
     std::vector<uint64_t> local_off(NK);  // offset of k-mer j inside its chunk
     std::vector<std::pair<uint64_t, uint64_t>> chunk_range(nt, {0, 0});
     std::atomic<uint64_t> n_closed{0};
+    std::atomic<bool> bad_leaf{false};
     parallel_chunks(NK, nt, [&](unsigned t, uint64_t lo, uint64_t hi) {
         chunk_range[t] = {lo, hi};
         std::vector<uint32_t>& W = chunk_words[t];
@@ -196,9 +221,18 @@ int encode_db(const cls_db_desc* d, EncodedDb& E, std::string& err) {
             for (uint64_t i = d->kmer_node_off[j]; i < d->kmer_node_off[j + 1]; ++i) {
                 uint32_t p = pre_of(d->node_ids[i]);
                 if (p != UINT32_MAX) P.push_back(p);  // ids that are no clade of this tree can never be asked for
+                if (leaves_only && (p == UINT32_MAX || !leaf_by_pre[p])) bad_leaf.store(true, std::memory_order_relaxed);
             }
             std::sort(P.begin(), P.end());
             P.erase(std::unique(P.begin(), P.end()), P.end());
+            local_off[j] = W.size();
+            if (leaves_only) {  // closed by construction: the tips ARE the leaves, the root is on every path
+                W.push_back((uint32_t)P.size() | (P.empty() ? 0u : POST_HAS_ROOT) | POST_CLOSED);
+                W.push_back((uint32_t)P.size());
+                W.insert(W.end(), P.begin(), P.end());
+                ++closed_cnt;
+                continue;
+            }
             bool has_root = !P.empty() && P[0] == 0;
             bool closed = true;
             stk.clear();
@@ -210,7 +244,6 @@ int encode_db(const cls_db_desc* d, EncodedDb& E, std::string& err) {
                 if (x != 0 && (stk.empty() || stk.back() != parent_pre[x])) closed = false;
                 stk.push_back(x);
             }
-            local_off[j] = W.size();
             size_t hdr = W.size();
             W.push_back(0);
             W.push_back(n_leaf);
@@ -227,6 +260,7 @@ int encode_db(const cls_db_desc* d, EncodedDb& E, std::string& err) {
         }
         n_closed += closed_cnt;
     });
+    if (bad_leaf.load()) { err = "leaves-only node sets hold an id that is no LEAF clade of the tree"; return CLS_E_BAD_DB; }
     // chunks that were not run (single-thread fallback) stay empty
     std::vector<uint64_t> chunk_base(nt + 1, 0);
     for (unsigned t = 0; t < nt; ++t) chunk_base[t + 1] = chunk_base[t] + chunk_words[t].size();
@@ -240,86 +274,138 @@ int encode_db(const cls_db_desc* d, EncodedDb& E, std::string& err) {
     std::vector<uint64_t> kmer_off(NK);
     for (unsigned t = 0; t < nt; ++t)
         for (uint64_t j = chunk_range[t].first; j < chunk_range[t].second; ++j) kmer_off[j] = chunk_base[t] + local_off[j];
-    // ---- 4b. split-tree form when the whole index allows it (see cls_device.h) -------
-    const uint64_t* d_kmer_hash = d->kmer_hash;
+    std::vector<uint64_t>().swap(local_off);
+    lap("tips per k-mer");
+    // ---- 4b. tip sets + split trees when the whole index allows it (see cls_device.h) -------
     E.strictly_binary = true;
     for (uint32_t r = 0; r < N; ++r)
         if (d->nodes[order[r]].n_children != 0 && d->nodes[order[r]].n_children != 2) { E.strictly_binary = false; break; }
-    // CLS_FORCE_LIST=1 keeps the sorted-list form (A/B experiments only)
-    E.format = (n_closed.load() == NK && getenv("CLS_FORCE_LIST") == nullptr) ? FMT_SPLIT : FMT_LIST;
+    E.format = (n_closed.load() == NK && !tuning().force_list && N < DIRECT_TIP_MASK) ? FMT_SPLIT : FMT_LIST;
+    std::vector<uint32_t> set_of;  // FMT_SPLIT: k-mer -> set id (>= 1)
     if (E.format == FMT_SPLIT) {
-        // k-mers with the SAME tip list (neighbouring k-mers of a conserved region) share one split tree:
-        // group them exactly (signature first, then the lists themselves).
-        std::vector<uint64_t> sig(NK);
+        if (NK >= (1ULL << 32) - 1) { err = "more than 2^32 - 2 k-mers"; return CLS_E_BAD_DB; }
+        auto words_of = [&](uint32_t j) { return &E.postings[kmer_off[j]]; };
+        // k-mers with the SAME node set (same tips, same root flag) share one set: group them exactly -- by a
+        // signature first, then by the lists themselves inside a run of equal signatures.
+        struct SigIdx { uint64_t sig; uint32_t j; };
+        std::vector<SigIdx> by_set(NK);
         parallel_chunks(NK, nt, [&](unsigned, uint64_t lo, uint64_t hi) {
             for (uint64_t j = lo; j < hi; ++j) {
-                const uint32_t* w = &E.postings[kmer_off[j]];
+                const uint32_t* w = words_of((uint32_t)j);
                 const uint32_t n = w[0] & POST_LEN_MASK;
-                uint64_t h = 0x9E3779B97F4A7C15ull ^ n;
+                uint64_t h = 0x9E3779B97F4A7C15ull ^ n ^ ((uint64_t)(w[0] & POST_HAS_ROOT) << 8);
                 for (uint32_t i = 0; i < n; ++i) h = fmix64(h ^ w[POST_HEADER_WORDS + i]) + 0x632BE59BD9B4E019ull;
-                sig[j] = h;
+                by_set[j] = {h, (uint32_t)j};
             }
         });
-        std::vector<uint32_t> by_set(NK);
-        if (NK >= (1ULL << 32)) { err = "more than 2^32 k-mers"; return CLS_E_BAD_DB; }
-        for (uint64_t j = 0; j < NK; ++j) by_set[j] = (uint32_t)j;
-        auto tips_of = [&](uint32_t j, uint32_t& n) { const uint32_t* w = &E.postings[kmer_off[j]]; n = w[0] & POST_LEN_MASK; return w + POST_HEADER_WORDS; };
-        auto cmp = [&](uint32_t a, uint32_t b) {
-            if (sig[a] != sig[b]) return sig[a] < sig[b];
-            uint32_t na, nb;
-            const uint32_t* ta = tips_of(a, na);
-            const uint32_t* tb = tips_of(b, nb);
-            if (na != nb) return na < nb;
-            const int c = na ? memcmp(ta, tb, (size_t)na * 4) : 0;
+        auto same_set = [&](uint32_t a, uint32_t b) {
+            const uint32_t *wa = words_of(a), *wb = words_of(b);
+            const uint32_t n = wa[0] & POST_LEN_MASK;
+            return wa[0] == wb[0] && (n == 0 || memcmp(wa + POST_HEADER_WORDS, wb + POST_HEADER_WORDS, (size_t)n * 4) == 0);
+        };
+        auto less_set = [&](uint32_t a, uint32_t b) {  // total order on node sets (then on the k-mer index)
+            const uint32_t *wa = words_of(a), *wb = words_of(b);
+            if (wa[0] != wb[0]) return wa[0] < wb[0];
+            const uint32_t n = wa[0] & POST_LEN_MASK;
+            const int c = n ? memcmp(wa + POST_HEADER_WORDS, wb + POST_HEADER_WORDS, (size_t)n * 4) : 0;
             return c != 0 ? c < 0 : a < b;
         };
-        parallel_sort(by_set, nt, cmp);
-        std::vector<uint32_t> set_of(NK), set_rep;  // k-mer -> set, set -> a k-mer that holds its tip list
-        std::vector<uint64_t> set_rec;                // set -> first split-node record
-        uint64_t n_recs = SPLIT_FIRST_REC + SPLIT_HEADER_RECS * NK;  // records 0/1: the dummy "no k-mer" header; then every k-mer's header
-        for (uint64_t i = 0; i < NK; ++i) {
-            const uint32_t j = by_set[i];
-            bool same = false;
-            if (i) {
-                const uint32_t p = by_set[i - 1];
-                uint32_t na, nb;
-                const uint32_t* ta = tips_of(p, na);
-                const uint32_t* tb = tips_of(j, nb);
-                same = sig[p] == sig[j] && na == nb && (na == 0 || memcmp(ta, tb, (size_t)na * 4) == 0);
-            }
-            if (!same) {
-                uint32_t n;
-                (void)tips_of(j, n);
-                set_rep.push_back(j);
-                set_rec.push_back(n_recs);
-                n_recs += n ? n - 1 : 0;
-            }
-            set_of[j] = (uint32_t)(set_rep.size() - 1);
+        lap("set signatures");
+        parallel_sort(by_set, nt, [&](const SigIdx& a, const SigIdx& b) { return a.sig != b.sig ? a.sig < b.sig : a.j < b.j; });
+        lap("sort by signature");
+        // (runs of equal signature that hold DIFFERENT sets -- a 64-bit collision -- are put in set order)
+        for (uint64_t i = 0; i < NK;) {
+            uint64_t e = i + 1;
+            bool mixed = false;
+            while (e < NK && by_set[e].sig == by_set[i].sig) { mixed |= !same_set(by_set[i].j, by_set[e].j); ++e; }
+            if (mixed) std::sort(by_set.begin() + (ptrdiff_t)i, by_set.begin() + (ptrdiff_t)e, [&](const SigIdx& a, const SigIdx& b) { return less_set(a.j, b.j); });
+            i = e;
         }
-        std::vector<uint64_t>().swap(sig);
-        std::vector<uint32_t>().swap(by_set);
-        if (n_recs >= (1ULL << 31)) { err = "split-tree postings exceed 2^31 records"; return CLS_E_BAD_DB; }
-        const uint64_t NS = set_rep.size();
+        // distinct sets, then numbered in ascending (first tip, last tip, size): reads that the locality order puts
+        // next to each other look up neighbouring set records and split trees
+        struct SetKey { uint32_t first, last, n, rep; };
+        std::vector<SetKey> keys;
+        std::vector<uint32_t> tmp_set(NK);  // k-mer -> provisional set number
+        {
+            // position i opens a new set iff its k-mer's set differs from its predecessor's; numbered by a prefix sum
+            std::vector<uint8_t> opens(NK);
+            parallel_chunks(NK, nt, [&](unsigned, uint64_t lo, uint64_t hi) {
+                for (uint64_t i = lo; i < hi; ++i) opens[i] = (i == 0 || !same_set(by_set[i - 1].j, by_set[i].j)) ? 1 : 0;
+            });
+            std::vector<uint64_t> chunk_first(nt + 1, 0);  // sets opened before each chunk
+            parallel_chunks(NK, nt, [&](unsigned t, uint64_t lo, uint64_t hi) {
+                uint64_t c = 0;
+                for (uint64_t i = lo; i < hi; ++i) c += opens[i];
+                chunk_first[t + 1] = c;
+            });
+            for (unsigned t = 0; t < nt; ++t) chunk_first[t + 1] += chunk_first[t];
+            keys.resize(chunk_first[nt]);
+            const bool chunked = !(nt <= 1 || NK < 4096);  // (parallel_chunks runs small inputs as ONE chunk numbered 0)
+            parallel_chunks(NK, nt, [&](unsigned t, uint64_t lo, uint64_t hi) {
+                uint64_t g = chunked ? chunk_first[t] : 0;
+                for (uint64_t i = lo; i < hi; ++i) {
+                    const uint32_t j = by_set[i].j;
+                    if (opens[i]) {
+                        const uint32_t* w = words_of(j);
+                        const uint32_t n = w[0] & POST_LEN_MASK;
+                        keys[g++] = {n ? w[POST_HEADER_WORDS] : 0xFFFFFFFFu, n ? w[POST_HEADER_WORDS + n - 1] : ((w[0] & POST_HAS_ROOT) ? 1u : 0u), n, j};
+                    }
+                    tmp_set[j] = (uint32_t)(g - 1);
+                }
+            });
+        }
+        std::vector<SigIdx>().swap(by_set);
+        const uint64_t NS = keys.size();
+        lap("distinct sets");
+        std::vector<uint32_t> rank(NS);  // provisional number -> position in the final order
+        {
+            std::vector<uint32_t> ord(NS);
+            for (uint64_t g = 0; g < NS; ++g) ord[g] = (uint32_t)g;
+            parallel_sort(ord, nt, [&](uint32_t a, uint32_t b) {
+                const SetKey &x = keys[a], &y = keys[b];
+                if (x.first != y.first) return x.first < y.first;
+                if (x.last != y.last) return x.last < y.last;
+                if (x.n != y.n) return x.n < y.n;
+                return less_set(x.rep, y.rep);
+            });
+            std::vector<SetKey> sorted(NS);
+            for (uint64_t g = 0; g < NS; ++g) { sorted[g] = keys[ord[g]]; rank[ord[g]] = (uint32_t)g; }
+            keys.swap(sorted);
+        }
+        set_of.resize(NK);
+        parallel_chunks(NK, nt, [&](unsigned, uint64_t lo, uint64_t hi) {
+            for (uint64_t j = lo; j < hi; ++j) set_of[j] = rank[tmp_set[j]] + 1;  // set 0 = "no such k-mer"
+        });
+        std::vector<uint32_t>().swap(tmp_set);
+        std::vector<uint32_t>().swap(rank);
         E.n_sets = NS;
-        std::vector<uint32_t> recs((n_recs + 1) * 4, 0);
-        recs[2] = 0xFFFFFFFFu;  // dummy header {0, 0, first tip = MAX, last tip = 0}: decodes to "inactive"
-        std::vector<uint32_t> set_root(NS, 0);
+        lap("set order");
+        // split records: set g owns (n - 1) of them from set_rec[g]
+        std::vector<uint64_t> set_rec(NS + 1);
+        uint64_t n_recs = 1;  // record 0: the dummy
+        for (uint64_t g = 0; g < NS; ++g) { set_rec[g] = n_recs; n_recs += keys[g].n ? keys[g].n - 1 : 0; }
+        set_rec[NS] = n_recs;
+        if (n_recs >= (1ULL << 32)) { err = "split trees exceed 2^32 records"; return CLS_E_BAD_DB; }
+        HugeVec<uint32_t> recs((n_recs + 1) * 4, 0);
+        recs[2] = 0xFFFFFFFFu;  // dummy {0, 0, first tip = MAX, 0}: decodes to "inactive"
+        E.sets.assign(NS + 1, SetRec{0u, 0xFFFFFFFFu, 0u, 0u});
         parallel_chunks(NS, nt, [&](unsigned, uint64_t lo, uint64_t hi) {
-            std::vector<uint32_t> d, stk, L, R, pos, span_lo, span_hi;
+            std::vector<uint32_t> dd, stk, L, R, pos, span_lo, span_hi;
             for (uint64_t g = lo; g < hi; ++g) {
-                uint32_t n;
-                const uint32_t* tip = tips_of(set_rep[g], n);
+                const uint32_t* w = words_of(keys[g].rep);
+                const uint32_t n = w[0] & POST_LEN_MASK;
+                const uint32_t* tip = w + POST_HEADER_WORDS;
                 const uint64_t base = set_rec[g];
-                d.assign(n, 0); L.assign(n, 0); R.assign(n, 0);
+                dd.assign(n, 0); L.assign(n, 0); R.assign(n, 0);
                 for (uint32_t i = 1; i < n; ++i) {  // depth of LCA(tip[i-1], tip[i])
                     uint32_t a = tip[i - 1];
                     while (!(tip[i] < a + size_by_pre[a])) a = parent_pre[a];
-                    d[i] = depth_by_pre[a];
+                    dd[i] = depth_by_pre[a];
                 }
                 stk.clear();
                 for (uint32_t i = 1; i < n; ++i) {  // Cartesian tree, shallowest LCA on top
                     uint32_t last = 0;
-                    while (!stk.empty() && d[stk.back()] > d[i]) { last = stk.back(); stk.pop_back(); }
+                    while (!stk.empty() && dd[stk.back()] > dd[i]) { last = stk.back(); stk.pop_back(); }
                     L[i] = last;
                     if (!stk.empty()) R[stk.back()] = i;
                     stk.push_back(i);
@@ -346,7 +432,6 @@ int encode_db(const cls_db_desc* d, EncodedDb& E, std::string& err) {
                     }
                 }
                 auto at = [&](uint32_t i) { return (uint32_t)(base + pos[i]); };
-                set_root[g] = root ? at(root) : 0;
                 for (uint32_t i = 1; i < n; ++i) {
                     uint32_t* t = &recs[(size_t)at(i) * 4];
                     t[0] = tip[i - 1];              // descending into the LEFT part: new last tip ...
@@ -354,125 +439,120 @@ int encode_db(const cls_db_desc* d, EncodedDb& E, std::string& err) {
                     t[2] = tip[i];                  // descending into the RIGHT part: new first tip ...
                     t[3] = R[i] ? at(R[i]) : 0;     // ... and its split
                 }
-            }
-        });
-        parallel_chunks(NK, nt, [&](unsigned, uint64_t lo, uint64_t hi) {
-            for (uint64_t j = lo; j < hi; ++j) {
-                const uint32_t* w = &E.postings[kmer_off[j]];
-                const uint32_t n = w[0] & POST_LEN_MASK;
-                const uint32_t* tip = w + POST_HEADER_WORDS;
-                uint32_t* h = &recs[(SPLIT_FIRST_REC + SPLIT_HEADER_RECS * j) * 4];
-                h[0] = w[0];
-                h[1] = set_root[set_of[j]];
-                h[2] = n ? tip[0] : 0xFFFFFFFFu;  // no tip below the root: the "inactive" state {MAX, 0}
-                h[3] = n ? tip[n - 1] : 0;
-                h[4] = w[1];  // n_leaf_ids (statistics)
-                h[5] = (uint32_t)d_kmer_hash[j];
-                h[6] = (uint32_t)(d_kmer_hash[j] >> 32);
-                h[7] = bucket_of[j];
+                uint32_t lg = 0;
+                while (lg < 31 && (1u << lg) <= n) ++lg;  // bit length: small = specific to a small clade
+                SetRec& sr = E.sets[g + 1];
+                sr.x = root ? at(root) : 0;
+                sr.vlo_lg = n ? ((lg << DIRECT_TIP_BITS) | tip[0]) : 0xFFFFFFFFu;
+                sr.vhi_root = (n ? tip[n - 1] : 0u) | ((w[0] & POST_HAS_ROOT) ? 0x80000000u : 0u);
+                sr.n_leaf = w[1];
             }
         });
         E.postings.swap(recs);
-        for (uint64_t j = 0; j < NK; ++j) kmer_off[j] = SPLIT_FIRST_REC + SPLIT_HEADER_RECS * j;
+        lap("split trees");
     }
-    // ---- 5. hash table -------------------------------------------------------------
+    // ---- 5. hash table (linear probing; parallel claims, then a duplicate check) -------------------------
     uint64_t cap = 16;
     while (cap < 2 * NK) cap <<= 1;
     if (cap >= (1ULL << 32)) { err = "k-mer table exceeds 2^32 slots"; return CLS_E_BAD_DB; }
-    E.table.assign(cap, Slot{0, SLOT_EMPTY});
     const uint64_t mask = cap - 1;
-    for (uint64_t j = 0; j < NK; ++j) {
-        uint64_t h = d->kmer_hash[j];
-        uint64_t off = kmer_off[j];
-        uint64_t i = h & mask;
-        while (E.table[i].loc != SLOT_EMPTY) {
-            if (E.table[i].hash == h) {
-                // HashMap<MinimizerKey, HashMap<u64,..>>: the same k-mer hash under two buckets (or twice
-                // in one bucket) cannot come out of `cls build-db` short of a 64-bit murmur collision.
-                err = "k-mer hash " + std::to_string(h) + " occurs more than once in the index (unsupported)";
-                return CLS_E_BAD_DB;
+    const bool split = E.format == FMT_SPLIT;
+    // FMT_SPLIT slots are TSlot{hash, set, bucket} (set != 0 <=> occupied); FMT_LIST slots Slot{hash, loc}
+    E.table.assign(cap, split ? Slot{0, 0} : Slot{0, SLOT_EMPTY});
+    {
+        // a slot is claimed by a compare-and-swap on its second word, then its hash is written; lookups only
+        // happen after every thread has joined
+        uint64_t* raw = reinterpret_cast<uint64_t*>(E.table.data());
+        const uint64_t empty = split ? 0ull : SLOT_EMPTY;
+        // specificity tier of a set (its locality-key class, cls_device.h): bit length of the tip count <= 3 / 6 / 9 / more
+        auto tier_of = [&](uint32_t sid) -> uint64_t { const uint32_t lg = E.sets[sid].vlo_lg >> DIRECT_TIP_BITS; return lg <= 3 ? 0 : lg <= 6 ? 1 : lg <= 9 ? 2 : 3; };
+        parallel_chunks(NK, nt, [&](unsigned, uint64_t lo, uint64_t hi) {
+            for (uint64_t j = lo; j < hi; ++j) {
+                const uint64_t h = d->kmer_hash[j];
+                const uint64_t val = split ? ((uint64_t)set_of[j] | (((uint64_t)bucket_of[j] | (tier_of(set_of[j]) << TIER_SHIFT)) << 32))
+                                           : ((kmer_off[j] << LOC_BUCKET_BITS) | bucket_of[j]);
+                for (uint64_t i = h & mask;; i = (i + 1) & mask) {
+                    uint64_t expect = empty;
+                    if (__atomic_load_n(&raw[2 * i + 1], __ATOMIC_RELAXED) == empty &&
+                        __atomic_compare_exchange_n(&raw[2 * i + 1], &expect, val, false, __ATOMIC_ACQ_REL, __ATOMIC_RELAXED)) {
+                        raw[2 * i] = h;
+                        break;
+                    }
+                }
             }
-            i = (i + 1) & mask;
-        }
-        E.table[i] = Slot{h, (off << LOC_BUCKET_BITS) | bucket_of[j]};
+        });
+        // HashMap<MinimizerKey, HashMap<u64,..>>: the same k-mer hash under two buckets (or twice in one bucket) cannot
+        // come out of `cls build-db` short of a 64-bit murmur collision: every occupied slot must be the FIRST slot
+        // of its probe sequence that holds its hash
+        std::atomic<bool> has_dup{false};
+        std::atomic<uint64_t> dup{0};
+        parallel_chunks(cap, nt, [&](unsigned, uint64_t lo, uint64_t hi) {
+            for (uint64_t s = lo; s < hi; ++s) {
+                if (raw[2 * s + 1] == empty) continue;
+                const uint64_t h = raw[2 * s];
+                for (uint64_t i = h & mask; i != s; i = (i + 1) & mask)  // (no empty slot between a hash's home and its slot)
+                    if (raw[2 * i] == h) { dup.store(h, std::memory_order_relaxed); has_dup.store(true, std::memory_order_relaxed); break; }
+            }
+        });
+        if (has_dup.load()) { err = "k-mer hash " + std::to_string(dup.load()) + " occurs more than once in the index (unsupported)"; return CLS_E_BAD_DB; }
     }
-    // ---- 6. direct table for small k -----------------------------------------------------
-    if (E.format == FMT_SPLIT && d->k_size <= DIRECT_MAX_K && N < DIRECT_TIP_MASK) {
+    lap("hash table");
+    // ---- 6. direct table for small k: 4^k set ids -----------------------------------------------------
+    if (split && d->k_size <= DIRECT_MAX_K && E.n_sets < SET_ID_MASK) {
         const uint32_t K = (uint32_t)d->k_size, M = (uint32_t)std::min<uint64_t>(d->m_size, d->k_size);
         const uint64_t n_codes = 1ULL << (2 * K);
-        E.direct.assign(4 * n_codes, 0);  // {record offset, root split, first tip | bit length << 27, last tip | has_root << 31}
-        for (uint64_t c = 0; c < n_codes; ++c) E.direct[4 * c + 2] = 0xFFFFFFFFu;
+        E.direct.assign(n_codes, 0);
+        const TSlot* tab = reinterpret_cast<const TSlot*>(E.table.data());
         std::atomic<bool> foreign{false};
         std::atomic<uint64_t> found{0};
         parallel_chunks(n_codes, nt, [&](unsigned, uint64_t lo, uint64_t hi) {
             static const char LETTER[4] = {'A', 'C', 'T', 'G'};  // code = (ascii >> 1) & 3
+            // most of the 4^k probes miss every cache of a table of gigabytes: hash a block of codes, prefetch their
+            // home slots, then probe
+            constexpr int B = 32;
             char buf[DIRECT_MAX_K + 1];
+            uint64_t hs[B];
             uint64_t cnt = 0;
-            for (uint64_t code = lo; code < hi; ++code) {
-                for (uint32_t i = 0; i < K; ++i) buf[i] = LETTER[(code >> (2 * i)) & 3];
-                const uint64_t h = murmur3_h1_bytes(buf, K);
-                for (uint64_t i = h & mask; E.table[i].loc != SLOT_EMPTY; i = (i + 1) & mask) {
-                    if (E.table[i].hash != h) continue;
-                    const uint64_t bkey = d->bucket_key[E.table[i].loc & LOC_BUCKET_MASK];
-                    if (bkey != (M ? murmur3_h1_bytes(buf, M) : 0ull)) foreign = true;
-                    const uint32_t off = (uint32_t)(E.table[i].loc >> LOC_BUCKET_BITS);
-                    const uint32_t n_tips = E.postings[(size_t)off * 4] & POST_LEN_MASK;
-                    uint32_t lg = 0;
-                    while (lg < 31 && (1u << lg) <= n_tips) ++lg;  // bit length: small = specific k-mer
-                    const uint32_t* hd = &E.postings[(size_t)off * 4];  // {n | flags, root split, first tip, last tip}
-                    uint32_t* e = &E.direct[4 * code];
-                    e[0] = off;
-                    e[1] = hd[1];
-                    e[2] = n_tips ? ((lg << DIRECT_TIP_BITS) | hd[2]) : 0xFFFFFFFFu;
-                    e[3] = (n_tips ? hd[3] : 0u) | ((hd[0] & POST_HAS_ROOT) ? 0x80000000u : 0u);
-                    ++cnt;
-                    break;
+            for (uint64_t c0 = lo; c0 < hi; c0 += B) {
+                const int nb = (int)std::min<uint64_t>(B, hi - c0);
+                for (int q = 0; q < nb; ++q) {
+                    const uint64_t code = c0 + q;
+                    for (uint32_t i = 0; i < K; ++i) buf[i] = LETTER[(code >> (2 * i)) & 3];
+                    hs[q] = murmur3_h1_bytes(buf, K);
+                    __builtin_prefetch(&tab[hs[q] & mask]);
+                }
+                for (int q = 0; q < nb; ++q) {
+                    const uint64_t code = c0 + q, h = hs[q];
+                    for (uint64_t i = h & mask; tab[i].set != 0; i = (i + 1) & mask) {
+                        if (tab[i].hash != h) continue;
+                        for (uint32_t t = 0; t < M; ++t) buf[t] = LETTER[(code >> (2 * t)) & 3];
+                        if (d->bucket_key[tab[i].bucket & (uint32_t)LOC_BUCKET_MASK] != (M ? murmur3_h1_bytes(buf, M) : 0ull)) foreign = true;
+                        E.direct[code] = tab[i].set | (tab[i].bucket & ~SET_ID_MASK);  // set id | tier << 30
+                        ++cnt;
+                        break;
+                    }
                 }
             }
             found += cnt;
         });
         // an entry filed under a bucket that is not its own prefix's, or a hash no enumerated k-mer
         // produces (k-mers with non-ACGT letters cannot be queried anyway): keep the generic probe path
-        if (foreign.load() || found.load() != NK) std::vector<uint32_t>().swap(E.direct);
+        if (foreign.load() || found.load() != NK) HugeVec<uint32_t>().swap(E.direct);
         if (!E.direct.empty()) {
-            // does every k-mer share its state (tip set, root flag) with its reverse complement?  True for an index
-            // built from both strands; the fast kernel then looks up one k-mer per window instead of two.
+            // does every k-mer share its set with its reverse complement?  True for an index built from both
+            // strands; the fast kernels then look up one k-mer per window instead of two.
             std::atomic<bool> asym{false};
             parallel_chunks(n_codes, nt, [&](unsigned, uint64_t lo, uint64_t hi) {
                 for (uint64_t code = lo; code < hi && !asym.load(std::memory_order_relaxed); ++code) {
                     uint64_t rc = 0;
                     for (uint32_t i = 0; i < K; ++i) rc |= (((code >> (2 * i)) & 3) ^ 2) << (2 * (K - 1 - i));  // complement = code ^ 2 (A0 <-> T2, C1 <-> G3)
-                    if (rc <= code) continue;
-                    const uint32_t* a = &E.direct[4 * code];
-                    const uint32_t* b = &E.direct[4 * rc];
-                    if ((a[0] != 0) != (b[0] != 0) || a[1] != b[1] || a[2] != b[2] || a[3] != b[3]) asym = true;
+                    if (rc > code && E.direct[code] != E.direct[rc]) asym = true;
                 }
             });
             E.canonical = !asym.load();
         }
     }
-    // ---- 7. without a direct table: the hash table once more, with the descent state inside the slots -----
-    if (E.format == FMT_SPLIT && E.direct.empty() && N < DIRECT_TIP_MASK && E.postings.size() * 4 < (1ULL << 32)) {
-        E.ftable.assign(cap, FSlot{0, 0, 0, 0xFFFFFFFFu, 0, 0, 0});
-        parallel_chunks(cap, nt, [&](unsigned, uint64_t lo, uint64_t hi) {
-            for (uint64_t i = lo; i < hi; ++i) {
-                const Slot& sl = E.table[i];
-                if (sl.loc == SLOT_EMPTY) continue;
-                const uint32_t off = (uint32_t)(sl.loc >> LOC_BUCKET_BITS);
-                const uint32_t* hd = &E.postings[(size_t)off * 4];  // {n | flags, root split, first tip, last tip}
-                const uint32_t n_tips = hd[0] & POST_LEN_MASK;
-                uint32_t lg = 0;
-                while (lg < 31 && (1u << lg) <= n_tips) ++lg;
-                FSlot& f = E.ftable[i];
-                f.hash = sl.hash;
-                f.off = off;
-                f.x = hd[1];
-                f.vlo_lg = n_tips ? ((lg << DIRECT_TIP_BITS) | hd[2]) : 0xFFFFFFFFu;
-                f.vhi_root = (n_tips ? hd[3] : 0u) | ((hd[0] & POST_HAS_ROOT) ? 0x80000000u : 0u);
-                f.bucket = (uint32_t)(sl.loc & LOC_BUCKET_MASK);
-            }
-        });
-    }
+    lap("direct table");
     E.bucket_key.assign(d->bucket_key, d->bucket_key + d->n_buckets);
     if (E.bucket_key.empty()) E.bucket_key.push_back(0);
     E.k = (uint32_t)d->k_size;

@@ -27,33 +27,30 @@ static_assert(sizeof(DNode) == 32, "DNode");
 // ---- k-mer table --------------------------------------------------------------
 // Open addressing, linear probing, power-of-two capacity, load <= 0.5.
 // key  = murmur3_x64_128(kmer,0).0 (kmers_map.rs:157-159)
-// loc  = postings word offset (40 bits) << 24 | minimizer-bucket index (24 bits)
+// FMT_LIST:  Slot{hash, loc}, loc = postings word offset (40 bits) << 24 | minimizer-bucket index (24 bits)
+// FMT_SPLIT: TSlot{hash, set, bucket}: the k-mer's tip set (index into `sets`, never 0 for a k-mer of the index:
+//            set == 0 marks an empty slot) and its minimizer bucket
 struct Slot {
     uint64_t hash;
     uint64_t loc;
 };
 static_assert(sizeof(Slot) == 16, "Slot");
 constexpr uint64_t SLOT_EMPTY = ~0ULL;
-// The same table with the k-mer's initial descent state inside the slot (FMT_SPLIT without a direct table, i.e.
-// k > 15): a hit needs no header read.  Same capacity, same probe sequence as `Slot`.
-//   off      header record of the k-mer (0 = empty slot)
-//   x        root split
-//   vlo_lg   first tip | bit_length(n_tips) << 27   (0xFFFFFFFF: no tip below the root)
-//   vhi_root last tip | has_root << 31
-struct FSlot {
+struct TSlot {
     uint64_t hash;
-    uint32_t off;
-    uint32_t x;
-    uint32_t vlo_lg;
-    uint32_t vhi_root;
-    uint32_t bucket;
-    uint32_t pad_;
+    uint32_t set;
+    uint32_t bucket;  // minimizer-bucket index (24 bits) | specificity tier of the set << 30
 };
-static_assert(sizeof(FSlot) == 32, "FSlot");
+// A direct-table entry and TSlot.bucket carry the set's specificity tier in their top two bits: the bit length of
+// its tip count is <= 3 (0), <= 6 (1), <= 9 (2) or larger / no tips at all (3).  The locality keys prefer the
+// k-mers that are specific to a small clade (order_key_kernel).
+constexpr int TIER_SHIFT = 30;
+constexpr uint32_t SET_ID_MASK = (1u << TIER_SHIFT) - 1;
+static_assert(sizeof(TSlot) == 16, "TSlot");
 constexpr int LOC_BUCKET_BITS = 24;
 constexpr uint64_t LOC_BUCKET_MASK = (1ULL << LOC_BUCKET_BITS) - 1;
 
-// ---- postings -----------------------------------------------------------------
+// ---- postings (FMT_LIST) --------------------------------------------------------
 // Per k-mer, at word offset `off` of the u32 postings array:
 //   w0 = n_elems | POST_HAS_ROOT | POST_CLOSED
 //   w1 = number of LEAF-kind ids in the original node set (statistics only)
@@ -67,36 +64,36 @@ constexpr uint32_t POST_CLOSED = 1u << 30;
 constexpr uint32_t POST_LEN_MASK = (1u << 30) - 1;
 constexpr uint32_t POST_HEADER_WORDS = 2;
 
-// ---- postings, "split-tree" form (FMT_SPLIT) ----------------------------------
-// Used when EVERY node set is closed under `parent` (every `cls build-db` output).  16-byte records; a k-mer with n tips owns 2 header
-// records + (n-1) split nodes:
-//   header 0 : {n | POST_HAS_ROOT | POST_CLOSED, root split (record index, 0 = none), first tip, last tip}
-//   header 1 : {n_leaf_ids (statistics), hash lo, hash hi, minimizer-bucket index}
-//   split i  : {tip[i-1], L, tip[i], R}            (1 <= i < n): one 8-byte half per direction
-// tip[] = ascending pre-order indices.  Split i is the node of the Cartesian tree
-// over depth(LCA(tip[i-1], tip[i])): for the tips inside one clade's interval the
-// shallowest such LCA is where the clade's two children part them, so L / R
-// (absolute record indices, 0 = none) are the splits of the left / right part.
-// Descending one level costs ONE 16-byte read per k-mer that has tips on both
-// sides, and none otherwise.  Split nodes are stored in DFS pre-order, heavier
-// child first, so the successive reads of one k-mer tend to share a 64-byte line.
-// Record 0/1 of the array are a dummy header pair {0, 0, 0xFFFFFFFF, 0}: "no k-mer"
-// reads land there and decode to an inactive state without a branch.
-constexpr uint32_t SPLIT_HEADER_RECS = 2;
-constexpr uint32_t SPLIT_FIRST_REC = 2;
-
-// ---- direct k-mer table (k <= DIRECT_MAX_K, FMT_SPLIT) ---------------------------------------
-// For small k every possible k-mer is enumerated once at cls_db_create(): its 2-bit
-// code (A=0 C=1 T=2 G=3 = (ascii >> 1) & 3, first base in the low bits) indexes a table
-// of 16-byte entries that hold the k-mer's whole initial descent state, so the query
-// side needs neither MurmurHash, nor a probe loop, nor the header record:
-//   {record offset of the header (0 = not in the index), root split,
-//    first tip | bit_length(n_tips) << 27   (0xFFFFFFFF: absent / no tip below the root),
-//    last tip  | has_root << 31}
-// The bit length feeds the locality ordering of cls_kernels.hip (order_key_kernel).
-// Only built when every index entry sits in the minimizer bucket of its own prefix (true
-// for every `cls build-db` output), which makes the bucket filter of kmers_map.rs:295-297
-// a no-op, and when pre-order indices fit DIRECT_TIP_BITS.
+// ---- tip sets + split trees (FMT_SPLIT) -----------------------------------------------
+// Used when EVERY node set is closed under `parent` (every `cls build-db` output): a node set is then the union
+// of the root->tip paths of its TIPS (members with no member below them), and `v in set` <=> some tip lies in
+// [pre(v), pre(v)+size(v)).  k-mers with the same (tips, has-root) share ONE set: neighbouring k-mers of a
+// conserved region, a k-mer and its reverse complement (C3: 459 k sets for 3.2 M k-mers).
+//   sets[s]    16 bytes {x, vlo_lg, vhi_root, n_leaf}; s = 0 is the "no such k-mer" set {0, MAX, 0, 0}
+//     x        record index of the set's root split (0: fewer than two tips)
+//     vlo_lg   first tip | bit_length(n_tips) << 27       (0xFFFFFFFF: no tip below the root)
+//     vhi_root last tip | has_root << 31
+//     n_leaf   LEAF-kind ids of the node set (statistics: cls_query_stats.leaf_postings)
+//   Sets are numbered in ascending (first tip, last tip): reads processed in locality order (below) touch
+//   neighbouring set records.  The bit length feeds the locality keys (order_key_kernel).
+//   splits[r]  16 bytes {tip[i-1], L, tip[i], R}: node i (1 <= i < n) of the Cartesian tree over
+//     depth(LCA(tip[i-1], tip[i])) of a set with n ascending tips.  For the tips inside one clade's interval the
+//     shallowest such LCA is where the clade's two children part them, so L / R (absolute record indices, 0 = none)
+//     are the splits of the left / right part: descending one level costs ONE 8-byte read (the half for the side
+//     taken) per set that has tips on both sides, and none otherwise.  Split nodes are stored per set, in DFS
+//     pre-order, heavier child first, so the successive reads of one set tend to share a 64-byte line.  Record 0
+//     is a dummy that decodes to "inactive" {0, 0, MAX, 0}.
+// The k-mer level is a plain map k-mer -> set: `direct` (k <= DIRECT_MAX_K: 4 bytes per possible k-mer, indexed by
+// its 2-bit code A=0 C=1 T=2 G=3 = (ascii >> 1) & 3, first base in the low bits) and/or the TSlot hash table.
+// The direct table is only built when every index entry sits in the minimizer bucket of its own prefix (true for
+// every `cls build-db` output), which makes the bucket filter of kmers_map.rs:295-297 a no-op.
+struct SetRec {
+    uint32_t x;
+    uint32_t vlo_lg;
+    uint32_t vhi_root;
+    uint32_t n_leaf;
+};
+static_assert(sizeof(SetRec) == 16, "SetRec");
 constexpr uint32_t DIRECT_MAX_K = 15;
 constexpr uint32_t DIRECT_TIP_BITS = 27;
 constexpr uint32_t DIRECT_TIP_MASK = (1u << DIRECT_TIP_BITS) - 1;
@@ -112,22 +109,23 @@ enum : uint32_t { FMT_LIST = 0, FMT_SPLIT = 1 };
 
 struct DbDev {
     const DNode* nodes;
-    const Slot* table;
-    const uint32_t* postings;   // FMT_LIST: u32 words; FMT_SPLIT: TipRec records (16-byte units)
+    const Slot* table;          // FMT_LIST: Slot; FMT_SPLIT: TSlot (same size, same probe sequence)
+    const uint32_t* postings;   // FMT_LIST: u32 words; FMT_SPLIT: TipRec split records (16-byte units)
     const uint64_t* bucket_key;
-    const uint32_t* direct;     // 4^k entries of 4 words (above) or nullptr
-    const FSlot* ftable;        // state-carrying hash table (above) or nullptr
+    const uint32_t* direct;     // FMT_SPLIT, k <= DIRECT_MAX_K: 4^k set ids, or nullptr
+    const SetRec* sets;         // FMT_SPLIT: tip sets
     uint64_t table_mask;
     uint32_t n_nodes;
     uint32_t n_buckets;
     uint32_t k;          // kSize
     uint32_t m_eff;      // min(mSize, kSize): chars().take(m), kmers_map.rs:11
     uint32_t max_nonleaf_arity;
-    uint32_t format;     // FMT_*; Slot.loc offsets are in words (LIST) or records (SPLIT)
-    uint32_t addr32;     // postings and direct table are both below 4 GiB: 32-bit byte offsets suffice
+    uint32_t format;     // FMT_*
+    uint32_t addr32;     // splits, sets and direct table are each below 4 GiB: 32-bit byte offsets suffice
     uint32_t binary_tree; // every clade has exactly zero or two children
-    uint32_t canonical;   // direct table: every k-mer and its reverse complement hold the same entry state (index built from both strands)
-    uint32_t hdr_bits;    // FMT_SPLIT: bits that hold any k-mer's header record offset (the sort key of the locality order)
+    uint32_t canonical;   // direct table: every k-mer and its reverse complement map to the same set (index built from both strands)
+    uint32_t set_bits;    // FMT_SPLIT: bits that hold any set id (the low part of the locality sort key)
+    uint32_t n_sets;      // FMT_SPLIT: entries of `sets` (incl. the dummy)
 };
 
 // Resolved Option<> arguments (place_sequence.rs:64-75)

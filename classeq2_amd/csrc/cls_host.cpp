@@ -28,6 +28,7 @@
 #include "cls_host_internal.h"
 #include "cls_json.h"
 #include "cls_murmur.h"
+#include "cls_tuning.h"
 
 namespace cls_host {
 
@@ -729,7 +730,7 @@ extern "C" int cls_place_sequences(cls_db* db, const cls_tree* t, const char* qu
         int rc = cls_place_fasta_text(db, text.data(), text.size(), params, &fa, &recs);
         if (rc != CLS_OK) { std::string m = cls_last_error(); return fail(rc, m); }
         std::string().swap(text);
-        const bool timing = getenv("CLS_TIMING") != nullptr;
+        const bool timing = cls::tuning().timing != 0;
         auto t2 = std::chrono::steady_clock::now();
         std::vector<std::string> po, pe;  // the pieces go to the files as they are: no second copy of 300 MB of text
         serialize_pieces(t, fa.headers, fa.header_off, fa.n, recs, format, po, pe);

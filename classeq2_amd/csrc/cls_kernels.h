@@ -24,6 +24,12 @@ struct PlacePlan {
     uint64_t long_set;         // entries of the distinct-hit set (power of two)
     uint64_t long_stride_words;
     uint64_t long_off_words;
+    uint32_t grid_tile;        // workgroups of the LDS-tiled long-read class (0: none in this launch)
+    uint32_t tile_threads;     // 512 (two workgroups per CU) or 1024
+    uint32_t tile_lookups;     // table lookups per read its LDS holds
+    uint32_t tile_bases;       // bases per read its LDS holds
+    uint32_t tile_cap_kmers;   // the same as a k-mer count (classification bound)
+    size_t tile_smem;          // dynamic LDS of that kernel
     uint64_t ws_bytes;         // device scratch the launch needs
 };
 // `long_cap`: k-mer capacity wanted for reads beyond MAX_READ_KMERS (0 = refuse them), `n_long`: how many

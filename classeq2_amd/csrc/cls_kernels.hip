@@ -26,6 +26,7 @@
 #include "cls_kernels.h"
 #include "cls_murmur.h"
 #include "cls_sort.h"
+#include "cls_tuning.h"
 
 namespace cls {
 
@@ -226,9 +227,9 @@ __device__ __forceinline__ void grp_sum4(uint32_t (&v)[4], uint32_t* red, uint32
 
 // Phases A0-A2 for one read, shared by both postings formats.  Returns false when the
 // read's record has already been written (error statuses); otherwise cx.ent[j] holds, for
-// query k-mer j < nk, the postings offset of its index entry if j is the FIRST query k-mer
-// with that hash and the entry passes the minimizer-bucket filter, else SET_EMPTY.
-template <int SLOTS, int SET_BITS, bool STATS, int WAVES = 1>
+// query k-mer j < nk, the postings offset (FMT_LIST) or the tip-set id (FMT_SPLIT) of its index entry
+// if j is the FIRST query k-mer with that hash and the entry passes the minimizer-bucket filter, else SET_EMPTY.
+template <int SLOTS, int SET_BITS, bool STATS, int WAVES = 1, bool SPLIT = false>
 __device__ __forceinline__ bool match_phase(const DbDev& db, const WaveCtx& cx, const uint8_t* __restrict__ bases,
                                             uint64_t b0, uint64_t b1, uint32_t r, cls_placement* __restrict__ out,
                                             cls_query_stats* __restrict__ stats, uint32_t& nk_out) {
@@ -299,8 +300,8 @@ __device__ __forceinline__ bool match_phase(const DbDev& db, const WaveCtx& cx, 
             uint64_t idx = h & db.table_mask;
 #pragma unroll 1
             for (;;) {
-                const Slot sl = db.table[idx];
-                if (sl.loc == SLOT_EMPTY) break;
+                const Slot sl = db.table[idx];  // FMT_SPLIT: TSlot{hash, set | bucket << 32}, set == 0: empty
+                if (SPLIT ? (uint32_t)sl.loc == 0u : sl.loc == SLOT_EMPTY) break;
                 if (sl.hash == h) { hit = true; loc = sl.loc; tidx = (uint32_t)idx; break; }
                 idx = (idx + 1) & db.table_mask;
             }
@@ -308,7 +309,7 @@ __device__ __forceinline__ bool match_phase(const DbDev& db, const WaveCtx& cx, 
         // the bucket's key must be one of the query's minimizers (kmers_map.rs:295-297)
         bool ok = false;
         uint64_t bk = 0;
-        if (hit) { bk = db.bucket_key[loc & LOC_BUCKET_MASK]; ok = (bk == mz); }
+        if (hit) { bk = db.bucket_key[SPLIT ? (uint32_t)(loc >> 32) & (uint32_t)LOC_BUCKET_MASK : (uint32_t)(loc & LOC_BUCKET_MASK)]; ok = (bk == mz); }
         uint64_t pend = __ballot(hit && !ok);
         while (pend) {  // never taken for an index built by `cls build-db`
             const int src = __ffsll((unsigned long long)pend) - 1;
@@ -330,7 +331,7 @@ __device__ __forceinline__ bool match_phase(const DbDev& db, const WaveCtx& cx, 
 #pragma unroll 1
             for (;;) {
                 const uint32_t old = atomicCAS(&cx.set[pos], SET_EMPTY, tidx);
-                if (old == SET_EMPTY) { ent = (uint32_t)(loc >> LOC_BUCKET_BITS); break; }
+                if (old == SET_EMPTY) { ent = SPLIT ? ((uint32_t)loc & 0x3FFFFFFFu) : (uint32_t)(loc >> LOC_BUCKET_BITS); break; }
                 if (old == tidx) break;
                 pos = (pos + 1) & ((1u << SET_BITS) - 1);
             }
@@ -575,24 +576,26 @@ __device__ __forceinline__ void place_read_split(const DbDev db, const PlacePara
     const uint32_t tid = WAVES == 1 ? lane : threadIdx.x;
     (void)tid;
     uint32_t nk = 0;
-    if (!match_phase<SLOTS, SET_BITS, STATS, WAVES>(db, cx, bases, b0, b1, r, out, stats, nk)) return;
+    if (!match_phase<SLOTS, SET_BITS, STATS, WAVES, true>(db, cx, bases, b0, b1, r, out, stats, nk)) return;
     if (profile_stop == 1) { write_record(out, r, 0xFE, (int32_t)cx.ent[lane], 0, 0, 0); return; }  // profiling aid only
     const uint4* __restrict__ recs = reinterpret_cast<const uint4*>(db.postings);
+    const uint4* __restrict__ sets = reinterpret_cast<const uint4*>(db.sets);  // {x, first tip | lg << 27, last tip | root << 31, n_leaf}
     uint32_t vlo[SLOTS], vhi[SLOTS], x[SLOTS];
     uint32_t act = 0, n_m = 0, n_root = 0;
     uint64_t leafp = 0;
 #pragma unroll
     for (int s = 0; s < SLOTS; ++s) {
         const uint32_t j = s * GS + tid;
-        const uint32_t off = (j < nk) ? cx.ent[j] : SET_EMPTY;
-        const bool is_new = off != SET_EMPTY;
-        const uint4 hd = recs[is_new ? off : 0u];  // {n | flags, root split, first tip, last tip}
-        if (STATS && is_new) leafp += recs[off + 1].x;
-        const bool has_root = is_new && (hd.x & POST_HAS_ROOT) != 0;
-        vlo[s] = hd.z;
-        vhi[s] = hd.w;
-        x[s] = hd.y;
-        if (has_root && (hd.x & POST_LEN_MASK)) act |= 1u << s;
+        const uint32_t sid = (j < nk) ? cx.ent[j] : SET_EMPTY;
+        const bool is_new = sid != SET_EMPTY;
+        const uint4 sr = sets[is_new ? sid : 0u];  // set 0: "no such k-mer" {0, MAX, 0, 0}
+        if (STATS && is_new) leafp += sr.w;
+        const bool has_root = is_new && (sr.z >> 31) != 0;
+        const bool has_tips = sr.y != 0xFFFFFFFFu;
+        vlo[s] = has_tips ? (sr.y & DIRECT_TIP_MASK) : 0xFFFFFFFFu;
+        vhi[s] = sr.z & 0x7FFFFFFFu;
+        x[s] = sr.x;
+        if (has_root && has_tips) act |= 1u << s;
         n_m += popc64(__ballot(is_new));
         n_root += popc64(__ballot(is_new && has_root));
     }
@@ -976,14 +979,14 @@ constexpr int FAST_SLOTS_NARROW = 5;       // slots of the narrow wave-per-read 
 constexpr uint32_t FAST_MAX_ARITY = 256;  // non-LEAF children per clade the fast path keeps counters for
 
 // Front of the fast path, shared with order_key_kernel: the read -> LDS (upper-cased, validated),
-// 2 bits per base, then per query k-mer its 2-bit code and the direct-table entry
-// {header offset, root split, first tip | bit length << 27, last tip | has_root << 31}.
+// 2 bits per base, then per query k-mer its 2-bit code and the direct-table entry `e` = set id | tier << 30
+// (0: the k-mer is not in the index); `key` = what makes the k-mer distinct (its code).
 // `canonical`: one lookup per window j < nk = nf, of the smaller of the k-mer and its reverse complement;
 // kw = how many distinct query k-mers the lookup stands for (2, or 1 for a palindrome).
 // Returns false if the read holds a character other than ACGT.
 template <int SLOTS, int SET_BITS, bool ADDR32>
 __device__ __forceinline__ bool fast_front(const DbDev& db, const FastCtx& cx, const uint8_t* __restrict__ bases, uint64_t b0,
-                                           uint32_t L, uint32_t nf, uint32_t nk, uint4 (&ent)[SLOTS], uint32_t (&kw)[SLOTS],
+                                           uint32_t L, uint32_t nf, uint32_t nk, uint32_t (&e)[SLOTS], uint32_t (&key)[SLOTS], uint32_t (&kw)[SLOTS],
                                            uint32_t sample_shift = 32, bool canonical = false, uint32_t table_bits = SET_BITS) {
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t k = db.k;
@@ -1038,8 +1041,9 @@ __device__ __forceinline__ bool fast_front(const DbDev& db, const FastCtx& cx, c
         // sample_shift < 32: look up only the k-mers whose scrambled code has its top bits clear (a content-
         // based sample, the same k-mers in every read that contains them); 32 = all
         const bool take = valid && (sample_shift >= 32 || ((code * 0x9E3779B1u) >> sample_shift) == 0);
-        const uint4 e = ldx<uint4, ADDR32>(direct, take ? code : 0u);
-        ent[s] = take ? e : uint4{0u, 0u, 0xFFFFFFFFu, 0u};
+        const uint32_t v = ldx<uint32_t, ADDR32>(direct, take ? code : 0u);
+        e[s] = take ? v : 0u;
+        key[s] = code;
         kw[s] = !take ? 0u : (canonical && !palindrome) ? 2u : 1u;  // canonical: the window stands for the k-mer and its reverse complement
     }
     return true;
@@ -1047,12 +1051,12 @@ __device__ __forceinline__ bool fast_front(const DbDev& db, const FastCtx& cx, c
 
 // The same front for an index WITHOUT a direct table (k > 15: the reference's default is k = 35): the read goes to
 // LDS as forward ++ reverse-complement ASCII, each k-mer is keyed by MurmurHash3 (kmers_map.rs:157-159), probed in
-// the HBM hash table and passed through the minimizer-bucket filter (kmers_map.rs:295-297; the wave-wide search for a
-// foreign bucket's key is never taken for built indexes); the table's slots carry the same entry as the direct
-// table: {header offset, root split, first tip | bit length << 27, last tip | has_root << 31} (FSlot, cls_device.h).
+// the HBM hash table (TSlot: one 16-byte read per probe) and passed through the minimizer-bucket filter
+// (kmers_map.rs:295-297; the wave-wide search for a foreign bucket's key is never taken for built indexes).
+// `e` = set id | tier << 30 as above, `key` = the table slot (distinct per k-mer hash).  `ib`: index bytes asked for.
 template <int SLOTS, int SET_BITS, bool ADDR32>
 __device__ __forceinline__ bool hash_front(const DbDev& db, const FastCtx& cx, const uint8_t* __restrict__ bases, uint64_t b0,
-                                           uint32_t L, uint32_t nf, uint32_t nk, uint4 (&ent)[SLOTS], uint32_t (&kw)[SLOTS],
+                                           uint32_t L, uint32_t nf, uint32_t nk, uint32_t (&e)[SLOTS], uint32_t (&key)[SLOTS], uint32_t (&kw)[SLOTS],
                                            uint32_t table_bits, uint32_t& ib) {
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t k = db.k, m_eff = db.m_eff;
@@ -1079,24 +1083,22 @@ __device__ __forceinline__ bool hash_front(const DbDev& db, const FastCtx& cx, c
         const uint32_t j = s * 64 + lane;
         bool hit = false;
         uint64_t mz = 0;
-        uint4 st = uint4{0u, 0u, 0xFFFFFFFFu, 0u};  // {off, root split, first tip | lg << 27, last tip | root << 31}
-        uint32_t bucket = 0;
+        uint32_t ent = 0, bucket = 0, slot = 0;
         if (j < nk) {
             const uint64_t h = murmur3_h1_lds(kmer_start(j), k);
             mz = murmur3_h1_lds(kmer_start(j), m_eff);  // the "minimizer": the hash of the first m characters (kmers_map.rs:10-13)
             uint64_t idx = h & db.table_mask;
-            const uint4* __restrict__ ft = reinterpret_cast<const uint4*>(db.ftable);  // slot = {hash lo, hash hi, off, x}{vlo_lg, vhi_root, bucket, -}
+            const uint4* __restrict__ ft = reinterpret_cast<const uint4*>(db.table);  // TSlot = {hash lo, hash hi, set, bucket | tier << 30}
 #pragma unroll 1
             for (;;) {
-                const uint4 a = ft[2 * idx];
+                const uint4 a = ft[idx];
                 ib += 16;
                 if (a.z == 0) break;  // empty slot
                 if ((((uint64_t)a.y << 32) | a.x) == h) {
-                    const uint4 b = ft[2 * idx + 1];
-                    ib += 16 + 8;  // second half of the slot + the bucket's key
                     hit = true;
-                    st = uint4{a.z, a.w, b.x, b.y};
-                    bucket = b.z;
+                    ent = a.z | (a.w & ~SET_ID_MASK);
+                    bucket = a.w & (uint32_t)LOC_BUCKET_MASK;
+                    slot = (uint32_t)idx;
                     break;
                 }
                 idx = (idx + 1) & db.table_mask;
@@ -1104,7 +1106,7 @@ __device__ __forceinline__ bool hash_front(const DbDev& db, const FastCtx& cx, c
         }
         bool ok = false;
         uint64_t bk = 0;
-        if (hit) { bk = db.bucket_key[bucket]; ok = (bk == mz); }
+        if (hit) { bk = db.bucket_key[bucket]; ok = (bk == mz); ib += 8; }
         uint64_t pend = __ballot(hit && !ok);
         while (pend) {  // the bucket's key may still be the minimizer of another query k-mer
             const int src = __ffsll((unsigned long long)pend) - 1;
@@ -1118,7 +1120,8 @@ __device__ __forceinline__ bool hash_front(const DbDev& db, const FastCtx& cx, c
             if ((int)lane == src) ok = any;
             pend &= pend - 1;
         }
-        ent[s] = (hit && ok) ? st : uint4{0u, 0u, 0xFFFFFFFFu, 0u};
+        e[s] = (hit && ok) ? ent : 0u;
+        key[s] = slot;
         kw[s] = (hit && ok) ? 1u : 0u;
     }
     return true;
@@ -1335,14 +1338,13 @@ __device__ __forceinline__ void place_read_fast(const DbDev& db, const PlacePara
     };
     if (L64 < k) { put_stats(0, 0, 0, 0); write_record(out, r, CLS_ERR_TOO_FEW_KMERS, 0, 0, 0, 0); return; }
     const uint32_t L = (uint32_t)L64, nf = L - k + 1, nk = 2 * nf;  // nk <= 64*SLOTS by classification
-    // ---- A1/A2. load + validate + 2-bit pack; per k-mer: code -> direct table ----------------------
+    // ---- A1/A2. load + validate + 2-bit pack; per k-mer: code -> direct table -> tip-set id ------------
     // CANON (an index in which every k-mer and its reverse complement carry the same tip set, i.e. one built from
     // both strands): the k-mers of window p on the two strands are reverse complements of each other, so ONE lookup
     // of the smaller of the two answers for both; half the lookups, half the slots.
     constexpr bool CANON = MODE == 1, HASHED = MODE == 2;  // MODE 0: direct table, both strands looked up
     constexpr int LS = CANON ? (SLOTS + 1) / 2 : SLOTS;
-    uint4 ent[LS];
-    uint32_t kw[LS];
+    uint32_t sid[LS], key[LS], kw[LS];
     // the wide class sizes its LDS tables by the read (clearing 3 x 2048 entries cost more than placing a 250 bp read)
     uint32_t tb = SET_BITS;
     if constexpr (SET_BITS > 9) {
@@ -1352,11 +1354,11 @@ __device__ __forceinline__ void place_read_fast(const DbDev& db, const PlacePara
         tb = uniform(tb);
     }
     bool valid_read;
-    uint32_t ib = 0;  // STATS: index bytes this lane asked for (table entries, node records, split halves)
-    if constexpr (HASHED) valid_read = hash_front<LS, SET_BITS, ADDR32>(db, cx, bases, b0, L, nf, nk, ent, kw, tb, ib);
+    uint32_t ib = 0;  // STATS: index bytes this lane asked for (table entries, set records, node records, split halves)
+    if constexpr (HASHED) valid_read = hash_front<LS, SET_BITS, ADDR32>(db, cx, bases, b0, L, nf, nk, sid, key, kw, tb, ib);
     else {
-        valid_read = fast_front<LS, SET_BITS, ADDR32>(db, cx, bases, b0, L, nf, CANON ? nf : nk, ent, kw, 32, CANON, tb);
-        if (STATS) for (int s = 0; s < LS; ++s) ib += kw[s] ? 16u : 0u;  // one 16-byte table entry per looked-up window
+        valid_read = fast_front<LS, SET_BITS, ADDR32>(db, cx, bases, b0, L, nf, CANON ? nf : nk, sid, key, kw, 32, CANON, tb);
+        if (STATS) for (int s = 0; s < LS; ++s) ib += kw[s] ? 4u : 0u;  // one 4-byte table entry per looked-up window
     }
     // cls_query_stats.index_bytes: written last, after the counters (put_stats clears the field)
     auto put_index_bytes = [&]() {
@@ -1370,30 +1372,63 @@ __device__ __forceinline__ void place_read_fast(const DbDev& db, const PlacePara
         write_record(out, r, CLS_ERR_INVALID_BASE, 0, 0, 0, 0);
         return;
     }
-    const uint32_t* __restrict__ recs = db.postings;
-    // distinct hashes: the FIRST k-mer that reaches an entry keeps it (HashSet<u64> semantics)
+    // distinct hashes: the FIRST k-mer with a given code (table slot) keeps its entry (HashSet<u64> semantics)
+    uint32_t nm_lane = 0;
 #pragma unroll
     for (int s = 0; s < LS; ++s) {
-        if (ent[s].x != 0) {
-            const uint32_t key = ent[s].x;
-            uint32_t pos = (key * 2654435761u) >> (32 - tb);
+        sid[s] &= SET_ID_MASK;  // (the tier bits only matter to the locality keys)
+        if (sid[s] != 0) {
+            uint32_t pos = (key[s] * 2654435761u) >> (32 - tb);
 #pragma unroll 1
             for (;;) {
-                const uint32_t old = atomicCAS(&cx.set[pos], SET_EMPTY, key);
+                const uint32_t old = atomicCAS(&cx.set[pos], SET_EMPTY, key[s]);
                 if (old == SET_EMPTY) break;
-                if (old == key) { ent[s] = uint4{0u, 0u, 0xFFFFFFFFu, 0u}; kw[s] = 0; break; }
+                if (old == key[s]) { sid[s] = 0; kw[s] = 0; break; }
                 pos = (pos + 1) & ((1u << tb) - 1);
             }
         }
+        nm_lane += sid[s] != 0 ? kw[s] : 0u;
     }
-    if (profile_stop == 1) { write_record(out, r, 0xFE, (int32_t)(ent[0].x + ent[LS - 1].x), 0, 0, 0); return; }  // profiling aid
-    // ---- A3. |M|, |M_root| (the descent state comes with the table entry: no header read) -----------------
-    uint32_t cnt = 0;  // |M| in bits 0..15, |M_root| in bits 16..31 (per lane, then summed)
+    if (profile_stop == 1) { write_record(out, r, 0xFE, (int32_t)(sid[0] + sid[LS - 1]), 0, 0, 0); return; }  // profiling aid
+    // ---- A4. group the k-mers by tip set ----------------------------------------------------------------
+    // k-mers with the same set stay together all the way down, so everything below runs on {set, number of k-mers}
+    // pairs: a 150 bp read has a few dozen of them.  The first k-mer to claim a set id owns the group; only the
+    // owners read the 16-byte set record.
+    uint32_t pos[LS];
+    uint32_t owner = 0;
+#pragma unroll
+    for (int s = 0; s < LS; ++s) {
+        pos[s] = 0;
+        if (sid[s] != 0) {
+            uint32_t p = (sid[s] * 2654435761u) >> (32 - tb);
+#pragma unroll 1
+            for (;;) {
+                const uint32_t old = atomicCAS(&cx.gkey[p], SET_EMPTY, sid[s]);
+                if (old == SET_EMPTY) { owner |= 1u << s; break; }
+                if (old == sid[s]) break;
+                p = (p + 1) & ((1u << tb) - 1);
+            }
+            atomicAdd(&cx.gcnt[p], kw[s]);
+            pos[s] = p;
+        }
+    }
+    const uint4* __restrict__ sets = reinterpret_cast<const uint4*>(db.sets);
+    uint4 sr[LS];  // {root split, first tip | lg << 27, last tip | has_root << 31, n_leaf}
+#pragma unroll
+    for (int s = 0; s < LS; ++s) {
+        sr[s] = ldx<uint4, ADDR32>(sets, ((owner >> s) & 1u) ? sid[s] : 0u);  // set 0: {0, MAX, 0, 0}
+        if (STATS && ((owner >> s) & 1u)) ib += 16;
+    }
+    wave_sync();
+#pragma unroll
+    for (int s = 0; s < LS; ++s) pos[s] = ((owner >> s) & 1u) ? cx.gcnt[pos[s]] : 0u;  // now: the group's weight
+    // ---- A3. |M|, |M_root| ---------------------------------------------------------------------------------
+    uint32_t cnt = nm_lane;  // |M| in bits 0..15, |M_root| in bits 16..31 (per lane, then summed)
     uint64_t leafp = 0;
 #pragma unroll
     for (int s = 0; s < LS; ++s) {
-        if (STATS) leafp += (uint64_t)kw[s] * ldx<uint4, ADDR32>(recs, ent[s].x + 1).x;  // record 1 (the dummy's second half) holds 0
-        cnt += (ent[s].x != 0 ? kw[s] : 0u) + ((ent[s].w >> 31) * kw[s] << 16);
+        cnt += ((sr[s].z >> 31) * pos[s]) << 16;
+        if (STATS) leafp += (uint64_t)pos[s] * sr[s].w;
     }
     cnt = wave_sum(cnt);
     const uint32_t n_m = cnt & 0xFFFFu, n_root = cnt >> 16;
@@ -1401,7 +1436,7 @@ __device__ __forceinline__ void place_read_fast(const DbDev& db, const PlacePara
         for (int o = 32; o > 0; o >>= 1) leafp += ((uint64_t)__shfl_xor((uint32_t)(leafp >> 32), o) << 32) | __shfl_xor((uint32_t)leafp, o);
         put_stats(nk, n_m, n_root, leafp);
     }
-    if (profile_stop == 2) { write_record(out, r, 0xFE, (int32_t)(ent[0].z + ent[LS - 1].w), 0, 0, 0); return; }
+    if (profile_stop == 2) { write_record(out, r, 0xFE, (int32_t)(sr[0].z + sr[LS - 1].w), 0, 0, 0); return; }
     // ---- B. thresholds ------------------------------------------------------------------------------
     if (n_m == 0) { put_index_bytes(); write_record(out, r, CLS_UNCLASSIFIABLE_NO_MATCH, 0, 0, 0, 0); return; }
     if (n_root == 0) { put_index_bytes(); write_record(out, r, CLS_UNCLASSIFIABLE_NO_ROOT, 0, 0, 0, 0); return; }
@@ -1414,44 +1449,17 @@ __device__ __forceinline__ void place_read_fast(const DbDev& db, const PlacePara
         const uint64_t exp_usize = (expected != expected) ? 0ull : (uint64_t)expected;
         if ((uint64_t)n_root < exp_usize) { put_index_bytes(); write_record(out, r, CLS_UNCLASSIFIABLE_COVERAGE, (int32_t)n_root, 0, 0, 0); return; }
     }
-    // ---- A4. group the k-mers by tip set ----------------------------------------------------------------
-    // k-mers with the same tip list (they share their split tree: same root split, or the same single tip)
-    // stay together all the way down, so the descent runs on {set, number of k-mers} pairs: a 150 bp read
-    // has a few dozen of them.  The first k-mer to claim a key owns the group; the groups are compacted into
-    // the staging area (64 per chunk; chunk 0 then lives in registers, the others stay in LDS).
+    // the groups that have tips below the root are compacted into the staging area (64 per chunk; chunk 0 then
+    // lives in registers, the others stay in LDS); the tables are dead from here on: the staging area lies over them
     uint32_t n_sets = 0;
-    {
-        uint32_t pos[LS];
-        uint32_t owner = 0;
+    wave_sync();
 #pragma unroll
-        for (int s = 0; s < LS; ++s) {
-            const uint32_t lo_ = ent[s].z & DIRECT_TIP_MASK, hi_ = ent[s].w & 0x7FFFFFFFu;
-            pos[s] = 0;
-            if (lo_ <= hi_) {  // has tips below the root (absent / tip-less entries hold {MAX, 0})
-                const uint32_t key = ent[s].y ? ent[s].y : (0x80000000u | lo_);
-                uint32_t p = (key * 2654435761u) >> (32 - tb);
-#pragma unroll 1
-                for (;;) {
-                    const uint32_t old = atomicCAS(&cx.gkey[p], SET_EMPTY, key);
-                    if (old == SET_EMPTY) { owner |= 1u << s; break; }
-                    if (old == key) break;
-                    p = (p + 1) & ((1u << tb) - 1);
-                }
-                atomicAdd(&cx.gcnt[p], kw[s]);
-                pos[s] = p;
-            }
-        }
-        wave_sync();
-#pragma unroll
-        for (int s = 0; s < LS; ++s) pos[s] = ((owner >> s) & 1u) ? cx.gcnt[pos[s]] : 0u;  // now: the group's weight
-        wave_sync();  // the tables are dead from here on: the staging area lies over them
-#pragma unroll
-        for (int s = 0; s < LS; ++s) {
-            const uint64_t m = __ballot((owner >> s) & 1u);
-            if ((owner >> s) & 1u)
-                cx.stage[n_sets + popc64(m & ((1ull << lane) - 1))] = uint4{ent[s].z & DIRECT_TIP_MASK, ent[s].w & 0x7FFFFFFFu, ent[s].y, pos[s]};
-            n_sets += popc64(m);
-        }
+    for (int s = 0; s < LS; ++s) {
+        const bool live = ((owner >> s) & 1u) && sr[s].y != 0xFFFFFFFFu;
+        const uint64_t m = __ballot(live);
+        if (live)
+            cx.stage[n_sets + popc64(m & ((1ull << lane) - 1))] = uint4{sr[s].y & DIRECT_TIP_MASK, sr[s].z & 0x7FFFFFFFu, sr[s].x, pos[s]};
+        n_sets += popc64(m);
     }
     descend_groups<(SLOTS * 64 < 1024), ADDR32, POLY, STATS>(db, prm, cx, n_sets, P, r, out, ib);
     put_index_bytes();
@@ -1505,15 +1513,28 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, SLOTS <= 5 ? FAST_MIN_WAVES :
     }
 }
 
-// Locality key of every read for the ordering above: among the read's k-mers present in the index the
-// most specific one (fewest tips; ties: smaller first tip, then smaller record offset) names a leaf
-// neighbourhood (its first tip) and, through its record offset, a group of overlapping reads.
+// Locality key of every read for the ordering above.  Among the read's k-mers present in the index, the ones
+// specific to a small clade (few tips: tier bits of the table entry; the bound is widened until a handful
+// qualify) name a leaf neighbourhood through the MEDIAN of their set ids (sets are numbered in ascending first
+// tip; the median is robust against the chance matches of sequencing errors, which land anywhere in the tree),
+// and a MinHash over the k-mers' codes names a group of overlapping reads.
+//   key_mode 0: {median set id >> block_shift, 16-bit MinHash of the specific k-mers}: leaf neighbourhood first
+//   key_mode 1: {20-bit MinHash of ALL present k-mers, median set id}: locus first
 // Reads the fast kernel will not place (too short / too long / bad characters) get the last key.
+__device__ __forceinline__ uint32_t mix32(uint32_t x) {
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    return x;
+}
+__device__ __forceinline__ uint64_t make_order_key(uint32_t key_mode, uint32_t median, uint32_t mh_spec, uint32_t mh_all, uint32_t block_shift, uint32_t set_bits) {
+    if (key_mode == 1) return ((uint64_t)(mh_all >> 12) << set_bits) | median;
+    return ((uint64_t)(median >> block_shift) << 16) | (mh_spec >> 16);
+}
+
 template <int SLOTS, bool ADDR32, bool FWD, bool HASHED>
 __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void order_key_kernel(DbDev db, const uint8_t* __restrict__ bases,
                                                                        const uint64_t* __restrict__ offsets, uint32_t n_reads,
                                                                        uint64_t* __restrict__ keys, uint32_t* __restrict__ idx,
-                                                                       uint32_t ascii_cap, uint32_t tip_bits, uint32_t spec_lg,
+                                                                       uint32_t ascii_cap, uint32_t key_mode,
                                                                        uint32_t block_shift, uint32_t sample_shift, uint32_t fwd_only,
                                                                        uint32_t key_cap) {
     extern __shared__ __align__(16) uint8_t smem[];
@@ -1537,50 +1558,52 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void order_key_kernel(DbDev d
             // (up to key_cap k-mers) too: the same sorted list then orders both wave-per-read kernels
             const uint32_t L = (uint32_t)std::min<uint64_t>(L64, 32 * SLOTS + db.k - 1), nf = L - db.k + 1, nk = 2 * nf;
             constexpr int LS = FWD ? (SLOTS + 1) / 2 : SLOTS;  // one lookup per window needs half the slots
-            uint4 ent[LS];
-            uint32_t kw[LS];
+            uint32_t e[LS], code[LS], kw[LS];
             // one lookup per window, of the smaller of the k-mer and its reverse complement: an index built from
             // both strands files the two under the same leaves, and the key then does not depend on the strand read
             bool valid_read;
             // (without a direct table FWD means "the forward k-mers only": the key then depends on the strand read)
             uint32_t ib_unused = 0;
-            if constexpr (HASHED) valid_read = hash_front<LS, 0, ADDR32>(db, cx, bases, b0, L, nf, FWD ? nf : nk, ent, kw, 0, ib_unused);
-            else valid_read = fast_front<LS, 0, ADDR32>(db, cx, bases, b0, L, nf, FWD ? nf : nk, ent, kw, sample_shift, FWD);
+            if constexpr (HASHED) valid_read = hash_front<LS, 0, ADDR32>(db, cx, bases, b0, L, nf, FWD ? nf : nk, e, code, kw, 0, ib_unused);
+            else valid_read = fast_front<LS, 0, ADDR32>(db, cx, bases, b0, L, nf, FWD ? nf : nk, e, code, kw, sample_shift, FWD);
             if (valid_read) {
-                // candidates: k-mers present in the index that are specific to a small clade (few tips);
-                // the tip bound is widened until a handful qualify (finally: every k-mer present)
                 uint32_t cand = 0, n_cand = 0;
-                uint32_t lg_max = spec_lg;
-                for (int tier = 0; tier < 4 && n_cand < 4; ++tier, lg_max = tier == 3 ? 31u : lg_max + 3u) {
+                for (uint32_t tier = 0; tier < 4 && n_cand < 4; ++tier) {
                     cand = 0; n_cand = 0;
 #pragma unroll
                     for (int s = 0; s < LS; ++s) {
-                        const bool c = ent[s].x != 0 && (ent[s].z >> DIRECT_TIP_BITS) <= lg_max;
+                        const bool c = (e[s] & SET_ID_MASK) != 0 && (e[s] >> TIER_SHIFT) <= tier;
                         cand |= (c ? 1u : 0u) << s;
                         n_cand += popc64(__ballot(c));
                     }
                 }
                 if (n_cand) {
-                    // median first tip of the candidates (robust against the chance matches of sequencing
-                    // errors, which land anywhere in the tree): radix select, one bit per round
+                    // median set id of the candidates: radix select, one bit per round
                     uint32_t rank = n_cand >> 1, prefix = 0;
-                    for (int bit = (int)tip_bits - 1; bit >= 0; --bit) {
+                    for (int bit = (int)db.set_bits - 1; bit >= 0; --bit) {
                         uint32_t c0 = 0;
 #pragma unroll
                         for (int s = 0; s < LS; ++s) {
-                            const uint32_t t = ent[s].z & DIRECT_TIP_MASK;
+                            const uint32_t t = e[s] & SET_ID_MASK;
                             const bool z = ((cand >> s) & 1u) && ((t ^ prefix) >> (bit + 1)) == 0 && !((t >> bit) & 1u);
                             c0 += popc64(__ballot(z));
                         }
                         if (rank >= c0) { rank -= c0; prefix |= 1u << bit; }
                     }
-                    // group of overlapping reads: the smallest record offset among the candidates (MinHash-like:
-                    // reads that share most of their specific k-mers share it)
-                    uint32_t mh = 0xFFFFFFFFu;
+                    // groups of overlapping reads: MinHash over the k-mers (reads that share most of them share it)
+                    uint32_t mh = 0xFFFFFFFFu, mha = 0xFFFFFFFFu;
 #pragma unroll
-                    for (int s = 0; s < LS; ++s) if ((cand >> s) & 1u) mh = ent[s].x < mh ? ent[s].x : mh;
-                    for (int o = 32; o > 0; o >>= 1) { const uint32_t other = __shfl_xor(mh, o); mh = other < mh ? other : mh; }
-                    key = ((uint64_t)(prefix >> block_shift) << db.hdr_bits) | mh;  // as few key bits as the index needs: fewer radix passes
+                    for (int s = 0; s < LS; ++s) {
+                        const uint32_t hsh = mix32(code[s]);
+                        if ((cand >> s) & 1u) mh = hsh < mh ? hsh : mh;
+                        if ((e[s] & SET_ID_MASK) != 0) mha = hsh < mha ? hsh : mha;
+                    }
+                    for (int o = 32; o > 0; o >>= 1) {
+                        const uint32_t o1 = __shfl_xor(mh, o), o2 = __shfl_xor(mha, o);
+                        mh = o1 < mh ? o1 : mh;
+                        mha = o2 < mha ? o2 : mha;
+                    }
+                    key = make_order_key(key_mode, prefix, mh, mha, block_shift, db.set_bits);
                 }
             }
             wave_sync();
@@ -1596,7 +1619,7 @@ template <bool ADDR32>
 __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void order_key_half_kernel(DbDev db, const uint8_t* __restrict__ bases,
                                                                             const uint64_t* __restrict__ offsets, uint32_t n_reads,
                                                                             uint64_t* __restrict__ keys, uint32_t* __restrict__ idx,
-                                                                            uint32_t tip_bits, uint32_t spec_lg, uint32_t block_shift,
+                                                                            uint32_t key_mode, uint32_t block_shift,
                                                                             uint32_t key_cap) {
     constexpr uint32_t MAXL = 64 + DIRECT_MAX_K - 1 + 1;  // first 64 windows
     constexpr uint32_t WORDS = (MAXL + 15) / 16 + 2;
@@ -1637,7 +1660,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void order_key_half_kernel(Db
             if (w < WORDS) packed[w] = acc;
         }
         wave_sync();
-        uint32_t off[2], meta[2];
+        uint32_t e[2], hs[2];
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             const uint32_t p = hl + 32 * s;
@@ -1649,42 +1672,49 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void order_key_half_kernel(Db
             rcc = ((rcc >> 1) & 0x55555555u) | ((rcc & 0x55555555u) << 1);
             rcc >>= (32 - 2 * k);
             code = rcc < code ? rcc : code;  // the same entry whichever strand was read
-            const uint4 e = ldx<uint4, ADDR32>(direct, valid ? code : 0u);
-            off[s] = valid ? e.x : 0u;
-            meta[s] = valid ? e.z : 0xFFFFFFFFu;
+            const uint32_t v = ldx<uint32_t, ADDR32>(direct, valid ? code : 0u);
+            e[s] = valid ? v : 0u;
+            hs[s] = mix32(code);
         }
         // candidates: k-mers present in the index that are specific to a small clade; widen the bound until a few qualify
-        uint32_t cand = 0, n_cand = 0, lg_max = spec_lg;
-        for (int tier = 0; tier < 4; ++tier, lg_max = tier == 3 ? 31u : lg_max + 3u) {
+        uint32_t cand = 0, n_cand = 0;
+        for (uint32_t tier = 0; tier < 4; ++tier) {
             const bool need = n_cand < 4;  // (per half; the other half may already be done)
             uint32_t c_new = 0, n_new = 0;
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
-                const bool c = off[s] != 0 && (meta[s] >> DIRECT_TIP_BITS) <= lg_max;
+                const bool c = (e[s] & SET_ID_MASK) != 0 && (e[s] >> TIER_SHIFT) <= tier;
                 c_new |= (c ? 1u : 0u) << s;
                 n_new += (uint32_t)__popc(half_of(__ballot(c)));
             }
             if (need) { cand = c_new; n_cand = n_new; }
             if (__ballot(n_cand < 4) == 0) break;
         }
-        // median first tip of the candidates: radix select, one bit per round
+        // median set id of the candidates: radix select, one bit per round
         uint32_t rank = n_cand >> 1, prefix = 0;
-        for (int bit = (int)tip_bits - 1; bit >= 0; --bit) {
+        for (int bit = (int)db.set_bits - 1; bit >= 0; --bit) {
             uint32_t c0 = 0;
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
-                const uint32_t t = meta[s] & DIRECT_TIP_MASK;
+                const uint32_t t = e[s] & SET_ID_MASK;
                 const bool z = ((cand >> s) & 1u) && ((t ^ prefix) >> (bit + 1)) == 0 && !((t >> bit) & 1u);
                 c0 += (uint32_t)__popc(half_of(__ballot(z)));
             }
             if (rank >= c0) { rank -= c0; prefix |= 1u << bit; }
         }
-        uint32_t mh = 0xFFFFFFFFu;
+        uint32_t mh = 0xFFFFFFFFu, mha = 0xFFFFFFFFu;
 #pragma unroll
-        for (int s = 0; s < 2; ++s) if ((cand >> s) & 1u) mh = off[s] < mh ? off[s] : mh;
-        for (int o = 16; o > 0; o >>= 1) { const uint32_t other = __shfl_xor(mh, o); mh = other < mh ? other : mh; }
+        for (int s = 0; s < 2; ++s) {
+            if ((cand >> s) & 1u) mh = hs[s] < mh ? hs[s] : mh;
+            if ((e[s] & SET_ID_MASK) != 0) mha = hs[s] < mha ? hs[s] : mha;
+        }
+        for (int o = 16; o > 0; o >>= 1) {
+            const uint32_t o1 = __shfl_xor(mh, o), o2 = __shfl_xor(mha, o);
+            mh = o1 < mh ? o1 : mh;
+            mha = o2 < mha ? o2 : mha;
+        }
         if (have && hl == 0) {
-            keys[r] = (ok && n_cand) ? (((uint64_t)(prefix >> block_shift) << db.hdr_bits) | mh) : ~0ull;
+            keys[r] = (ok && n_cand) ? make_order_key(key_mode, prefix, mh, mha, block_shift, db.set_bits) : ~0ull;
             idx[r] = r;
         }
         wave_sync();
@@ -1811,14 +1841,14 @@ __global__ __launch_bounds__(LONG_THREADS) void place_long_kernel(DbDev db, Plac
             if (use_direct) {
                 uint32_t code = 0;
                 for (uint32_t t = 0; t < k; ++t) code |= (uint32_t)((kmer_char(j, t) >> 1) & 3u) << (2 * t);  // A0 C1 T2 G3, first base in the low bits
-                const uint32_t off = db.direct[4 * (size_t)code];  // header record of the k-mer, 0 = not in the index
+                const uint32_t sid = db.direct[code] & SET_ID_MASK;  // tip set of the k-mer, 0 = not in the index
                 uint32_t e = SET_EMPTY;
-                if (off) {
-                    uint32_t pos = (off * 2654435761u) & (set_size - 1);
+                if (sid) {  // distinct k-mers are distinct codes
+                    uint32_t pos = (code * 2654435761u) & (set_size - 1);
                     for (;;) {
-                        const uint32_t old = atomicCAS(&set[pos], SET_EMPTY, off);
-                        if (old == SET_EMPTY) { e = off; break; }
-                        if (old == off) break;
+                        const uint32_t old = atomicCAS(&set[pos], SET_EMPTY, code);
+                        if (old == SET_EMPTY) { e = sid; break; }
+                        if (old == code) break;
                         pos = (pos + 1) & (set_size - 1);
                     }
                 }
@@ -1832,14 +1862,14 @@ __global__ __launch_bounds__(LONG_THREADS) void place_long_kernel(DbDev db, Plac
             uint32_t tidx = 0;
             uint64_t idx = h & db.table_mask;
             for (;;) {
-                const Slot sl = db.table[idx];
-                if (sl.loc == SLOT_EMPTY) break;
+                const Slot sl = db.table[idx];  // FMT_SPLIT: TSlot{hash, set | bucket << 32}, set == 0: empty
+                if (SPLIT ? (uint32_t)sl.loc == 0u : sl.loc == SLOT_EMPTY) break;
                 if (sl.hash == h) { hit = true; loc = sl.loc; tidx = (uint32_t)idx; break; }
                 idx = (idx + 1) & db.table_mask;
             }
             bool ok = false;
             if (hit) {
-                const uint64_t bk = db.bucket_key[loc & LOC_BUCKET_MASK];
+                const uint64_t bk = db.bucket_key[SPLIT ? (uint32_t)(loc >> 32) & (uint32_t)LOC_BUCKET_MASK : (uint32_t)(loc & LOC_BUCKET_MASK)];
                 ok = bk == mz;
                 if (!ok) {  // the bucket's key may still be the minimizer of another query k-mer (kmers_map.rs:295-297)
                     for (uint32_t jj = 0; jj < nk && !ok; ++jj)
@@ -1851,7 +1881,7 @@ __global__ __launch_bounds__(LONG_THREADS) void place_long_kernel(DbDev db, Plac
                 uint32_t pos = (tidx * 2654435761u) & (set_size - 1);
                 for (;;) {
                     const uint32_t old = atomicCAS(&set[pos], SET_EMPTY, tidx);
-                    if (old == SET_EMPTY) { e = (uint32_t)(loc >> LOC_BUCKET_BITS); break; }
+                    if (old == SET_EMPTY) { e = SPLIT ? (uint32_t)loc : (uint32_t)(loc >> LOC_BUCKET_BITS); break; }
                     if (old == tidx) break;
                     pos = (pos + 1) & (set_size - 1);
                 }
@@ -1874,11 +1904,11 @@ __global__ __launch_bounds__(LONG_THREADS) void place_long_kernel(DbDev db, Plac
                 uint32_t st[LONG_STATE_WORDS] = {0, 0, 0, 0, 0};
                 if (is_new) {
                     if constexpr (SPLIT) {
-                        const uint4 hd = recs[off];
-                        if (STATS) leafp += recs[off + 1].x;
-                        has_root = (hd.x & POST_HAS_ROOT) != 0;
-                        active = has_root && (hd.x & POST_LEN_MASK) != 0;
-                        st[0] = hd.z; st[1] = hd.w; st[2] = hd.y;
+                        const SetRec sr = db.sets[off];  // (`off` is the tip-set id here)
+                        if (STATS) leafp += sr.n_leaf;
+                        has_root = (sr.vhi_root >> 31) != 0;
+                        active = has_root && sr.vlo_lg != 0xFFFFFFFFu;
+                        st[0] = sr.vlo_lg & DIRECT_TIP_MASK; st[1] = sr.vhi_root & 0x7FFFFFFFu; st[2] = sr.x;
                     } else {
                         const uint32_t w0 = post[off];
                         if (STATS) leafp += post[off + 1];
@@ -2079,20 +2109,263 @@ __global__ __launch_bounds__(LONG_THREADS) void place_long_kernel(DbDev db, Plac
     }
 }
 
+// ---- long reads, LDS-tiled: one WORKGROUP per read, every per-k-mer state in LDS -----------------------------
+// BASELINE config 5 (10 kb reads, k = 15, deep tree).  For FMT_SPLIT indexes with a direct table on binary trees:
+//   front   the read packed 2 bits per base in LDS; per window (canonical index: one lookup for both strands) the
+//           2-bit code -> direct table -> tip-set id; distinct k-mers through an LDS set of codes that is filled in
+//           PASSES over hash partitions of the codes (a 16 KB set serves a read of any length); the first k-mer
+//           with a code reads its 16-byte set record and, if the set has tips, appends {first tip, last tip,
+//           weight | split} to the read's state arrays in LDS (12 bytes per distinct matching k-mer);
+//   descent every thread owns the same state entries at every level: count pass (3 compares per entry, one DPP
+//           reduction per wave, two LDS atomics per wave), ONE barrier, the decision (node records through the
+//           scalar unit), narrow pass (one 8-byte split half per entry with tips on both sides).  No state ever
+//           leaves the CU; per level the only global reads are the chosen child's node record and the split halves.
+// A read whose codes overflow a partition of the set (only an adversarial read can) is handed to the workspace
+// kernel below through the spill list: no input can make the probing loop spin.
+constexpr uint32_t TILE_SET_ENTRIES = 4096;      // LDS set of codes per pass (16 KB)
+constexpr uint32_t TILE_PASS_CODES = 1536;       // lookups per pass: load <= 0.375 for hash-partitioned distinct codes
+constexpr uint32_t TILE_TIP_BITS = 24;           // pre-order indices the packed state holds
+constexpr uint32_t TILE_TIP_MASK = (1u << TILE_TIP_BITS) - 1;
+struct TileSh {
+    uint32_t cnt[3][2];      // rotating per-level counters {in a | in b << 16, in both}
+    uint32_t n_groups;
+    uint32_t n_m, n_root;
+    uint32_t overflow;
+    uint32_t ib;
+    unsigned long long leafp;
+};
+__host__ __device__ inline uint32_t tile_packed_words(uint32_t max_bases) { return ((max_bases + 15) / 16 + 2 + 3) & ~3u; }
+// dynamic LDS of the tile kernel for reads of up to `max_lookups` table lookups and `max_bases` bases
+__host__ __device__ inline size_t tile_smem(uint32_t max_lookups, uint32_t max_bases) {
+    return 4ull * tile_packed_words(max_bases) + 4ull * TILE_SET_ENTRIES + 8ull * max_lookups + 4ull * max_lookups + 16;
+}
+
+template <int THREADS, bool CANON, bool STATS, bool ADDR32>
+__global__ __launch_bounds__(THREADS) void place_tile_kernel(DbDev db, PlaceParams prm, const uint8_t* __restrict__ bases,
+                                                             const uint64_t* __restrict__ offsets, const uint32_t* __restrict__ list,
+                                                             const uint32_t* __restrict__ list_len, cls_placement* __restrict__ out,
+                                                             cls_query_stats* __restrict__ stats, uint32_t max_lookups, uint32_t max_bases,
+                                                             uint32_t pass_codes, uint32_t* __restrict__ spill_list, uint32_t* __restrict__ spill_len) {
+    extern __shared__ __align__(16) uint8_t smem[];
+    __shared__ TileSh sh;
+    uint32_t* const packed = reinterpret_cast<uint32_t*>(smem);
+    uint32_t* const cset = packed + tile_packed_words(max_bases);
+    uint64_t* const hot = reinterpret_cast<uint64_t*>(cset + TILE_SET_ENTRIES);   // {first tip : 24, last tip : 24, weight : 16}
+    uint32_t* const xs = reinterpret_cast<uint32_t*>(hot + max_lookups);           // root split of the entry's set
+    const uint32_t tid = threadIdx.x, lane = tid & 63;
+    const uint32_t k = db.k;
+    const uint32_t kmask = (1u << (2 * k)) - 1u;  // k <= 15
+    const uint32_t* __restrict__ direct = db.direct;
+    const uint4* __restrict__ sets = reinterpret_cast<const uint4*>(db.sets);
+    const uint32_t* __restrict__ half = db.postings;  // split record x = 8-byte halves 2x (left part), 2x + 1 (right part)
+    const bool rm = prm.remove_intersection != 0;
+    const uint32_t n_list = *list_len;
+    for (uint32_t li = blockIdx.x; li < n_list; li += gridDim.x) {
+        __syncthreads();  // the previous read's use of the LDS is over
+        const uint32_t r = list[li];
+        const uint64_t b0 = offsets[r], L64 = offsets[r + 1] - b0;
+        auto put_stats = [&](uint32_t nk_, uint32_t nm, uint32_t nr, uint64_t lp, uint32_t ibytes) {
+            if (STATS && stats && tid == 0) {
+                uint64_t* s = reinterpret_cast<uint64_t*>(stats + r);
+                s[0] = (uint64_t)nk_ | ((uint64_t)nm << 32);
+                s[1] = (uint64_t)nr | ((uint64_t)ibytes << 32);
+                s[2] = lp;
+            }
+        };
+        auto record = [&](uint32_t status, int32_t one, int32_t rest, uint32_t levels, uint64_t clade) {
+            if (tid == 0) {
+                uint64_t* o = reinterpret_cast<uint64_t*>(out + r);
+                o[0] = (uint64_t)(status & 0xFF) | ((uint64_t)(uint32_t)one << 32);
+                o[1] = (uint64_t)(uint32_t)rest | ((uint64_t)levels << 32);
+                o[2] = clade;
+            }
+        };
+        // (classification keeps L >= k and the lookups within max_lookups; checked all the same: never trust a list)
+        if (L64 < k || L64 > max_bases) { put_stats(0, 0, 0, 0, 0); record(L64 < k ? CLS_ERR_TOO_FEW_KMERS : CLS_ERR_READ_TOO_LONG, 0, 0, 0, 0); continue; }
+        const uint32_t L = (uint32_t)L64, nf = L - k + 1, nk = 2 * nf;
+        const uint32_t n_look = CANON ? nf : nk;
+        if (n_look > max_lookups) { put_stats(nk, 0, 0, 0, 0); record(CLS_ERR_READ_TOO_LONG, 0, 0, 0, 0); continue; }
+        // ---- A1. load, validate (reverse_complement panics on non-ACGT, kmers_map.rs:440), pack 2 bits per base ----
+        bool bad = false;
+        const uint32_t n_words = (L + 15) >> 4;
+        for (uint32_t w = tid; w < n_words + 2; w += THREADS) {
+            uint32_t acc = 0;
+            for (uint32_t q = 0; q < 16; ++q) {
+                const uint32_t i = 16 * w + q;
+                if (i >= L) break;
+                uint8_t c = bases[b0 + i];
+                if (c >= 'a' && c <= 'z') c -= 32;
+                bad |= !(c == 'A' || c == 'C' || c == 'G' || c == 'T');
+                acc |= (uint32_t)((c >> 1) & 3u) << (2 * q);  // A0 C1 T2 G3
+            }
+            packed[w] = acc;
+        }
+        if (tid == 0) { sh.n_groups = 0; sh.n_m = 0; sh.n_root = 0; sh.overflow = 0; sh.ib = 0; sh.leafp = 0; }
+        if (tid < 6) (&sh.cnt[0][0])[tid] = 0;
+        if (__syncthreads_or(bad ? 1 : 0)) { put_stats(0, 0, 0, 0, 0); record(CLS_ERR_INVALID_BASE, 0, 0, 0, 0); continue; }
+        // ---- A2. lookups, distinct k-mers, state entries ----------------------------------------------------------
+        const uint32_t n_pass = (n_look + pass_codes - 1) / pass_codes;
+        uint32_t nm_t = 0, nroot_t = 0, ib_t = 0;
+        uint64_t leafp_t = 0;
+        for (uint32_t pass = 0; pass < n_pass; ++pass) {
+            if (pass) __syncthreads();  // the previous pass' set is no longer probed
+            for (uint32_t i = tid; i < TILE_SET_ENTRIES; i += THREADS) cset[i] = SET_EMPTY;
+            __syncthreads();
+            for (uint32_t base = 0; base < n_look; base += THREADS) {
+                const uint32_t j = base + tid;
+                bool mine = false;
+                uint32_t code = 0, kw = 0;
+                if (j < n_look) {
+                    const bool rc = j >= nf;
+                    const uint32_t p = rc ? (nf - 1) - (j - nf) : j;  // window start; the rc list runs backwards over the windows
+                    const uint32_t w = p >> 4, s2 = (2 * p) & 31;
+                    const uint32_t d0 = packed[w], d1 = packed[w + 1];
+                    code = (uint32_t)((((uint64_t)d1 << 32) | d0) >> s2) & kmask;
+                    uint32_t rcc = __builtin_bitreverse32(code ^ (0xAAAAAAAAu & kmask));
+                    rcc = ((rcc >> 1) & 0x55555555u) | ((rcc & 0x55555555u) << 1);
+                    rcc >>= (32 - 2 * k);
+                    const bool palindrome = code == rcc;
+                    code = CANON ? (rcc < code ? rcc : code) : (rc ? rcc : code);
+                    kw = (CANON && !palindrome) ? 2u : 1u;
+                    mine = n_pass == 1 || (uint32_t)(((uint64_t)mix32(code) * n_pass) >> 32) == pass;
+                }
+                uint32_t sid = 0;
+                if (mine) { sid = ldx<uint32_t, ADDR32>(direct, code) & SET_ID_MASK; if (STATS) ib_t += 4; }
+                bool first = false;
+                if (sid) {  // HashSet<u64> of hashes: the first k-mer with this code keeps the entry
+                    uint32_t pos = (code * 2654435761u) & (TILE_SET_ENTRIES - 1);
+                    for (uint32_t probes = 0;; ++probes) {
+                        if (probes == TILE_SET_ENTRIES) { sh.overflow = 1; break; }  // (a partition that does not fit: spill the read)
+                        const uint32_t old = atomicCAS(&cset[pos], SET_EMPTY, code);
+                        if (old == SET_EMPTY) { first = true; break; }
+                        if (old == code) break;
+                        pos = (pos + 1) & (TILE_SET_ENTRIES - 1);
+                    }
+                }
+                uint4 sr = uint4{0u, 0xFFFFFFFFu, 0u, 0u};
+                if (first) { sr = ldx<uint4, ADDR32>(sets, sid); if (STATS) ib_t += 16; }
+                const bool has_root = (sr.z >> 31) != 0, has_tips = sr.y != 0xFFFFFFFFu;
+                if (first) { nm_t += kw; nroot_t += has_root ? kw : 0u; if (STATS) leafp_t += (uint64_t)kw * sr.w; }
+                const bool live = first && has_root && has_tips;
+                const uint32_t g = append_slot(live, &sh.n_groups);
+                if (live) {
+                    hot[g] = (uint64_t)(sr.y & TILE_TIP_MASK) | ((uint64_t)(sr.z & TILE_TIP_MASK) << TILE_TIP_BITS) | ((uint64_t)kw << (2 * TILE_TIP_BITS));
+                    xs[g] = sr.x;
+                }
+            }
+        }
+        {   // |M|, |M_root| (and the statistics) over the workgroup
+            const uint32_t a = wave_sum(nm_t), b = wave_sum(nroot_t);
+            if (lane == 0) { if (a) atomicAdd(&sh.n_m, a); if (b) atomicAdd(&sh.n_root, b); }
+            if (STATS) {
+                for (int o = 32; o > 0; o >>= 1) leafp_t += ((uint64_t)__shfl_xor((uint32_t)(leafp_t >> 32), o) << 32) | __shfl_xor((uint32_t)leafp_t, o);
+                if (lane == 0 && leafp_t) atomicAdd(&sh.leafp, (unsigned long long)leafp_t);
+            }
+        }
+        __syncthreads();
+        if (sh.overflow) {  // hand the read to the workspace kernel
+            if (tid == 0) spill_list[atomicAdd(spill_len, 1u)] = r;
+            continue;
+        }
+        const uint32_t n_m = sh.n_m, n_root = sh.n_root, n_groups = sh.n_groups;
+        uint32_t ib = ib_t;  // per thread; summed at the end
+        auto finish_stats = [&]() {
+            if constexpr (STATS) {
+                const uint32_t w = wave_sum(ib);
+                if (lane == 0 && w) atomicAdd(&sh.ib, w);
+                __syncthreads();
+                put_stats(nk, n_m, n_root, (uint64_t)sh.leafp, sh.ib);
+            }
+        };
+        // ---- B. thresholds (as in place_read_fast) ------------------------------------------------------------------
+        if (n_m == 0) { finish_stats(); record(CLS_UNCLASSIFIABLE_NO_MATCH, 0, 0, 0, 0); continue; }
+        if (n_root == 0) { finish_stats(); record(CLS_UNCLASSIFIABLE_NO_ROOT, 0, 0, 0, 0); continue; }
+        snode_t P = load_node(db.nodes, 0);
+        if (STATS && tid == 0) ib += 32;
+        if (!(P.s[7] & 1u)) { finish_stats(); record(CLS_ERR_ROOT_NO_CHILDREN, 0, 0, 0, 0); continue; }
+        {
+            const double expected = round((double)n_m * prm.min_match_coverage);
+            const uint64_t exp_usize = (expected != expected) ? 0ull : (uint64_t)expected;
+            if ((uint64_t)n_root < exp_usize) { finish_stats(); record(CLS_UNCLASSIFIABLE_COVERAGE, (int32_t)n_root, 0, 0, 0); continue; }
+        }
+        // ---- C. descent ---------------------------------------------------------------------------------------------
+        int32_t iteration = 0;
+        for (;;) {
+            ++iteration;
+            if (iteration > prm.max_iterations) { record(CLS_ERR_MAX_ITER, 0, 0, (uint32_t)iteration, 0); break; }
+            const uint32_t fc = P.s[2], m = P.s[3];
+            const uint32_t a0 = P.s[0] + 1, a1 = P.s[6];  // first child = [a0, a1), second = [a1, end of the parent)
+            uint32_t c_ab = 0, c_both = 0;  // k-mers in a | in b << 16; in both (weights: at most 2 * nf < 2^16)
+            for (uint32_t j = tid; j < n_groups; j += THREADS) {
+                const uint64_t h = hot[j];
+                const uint32_t lo_ = (uint32_t)h & TILE_TIP_MASK, hi_ = (uint32_t)(h >> TILE_TIP_BITS) & TILE_TIP_MASK, w = (uint32_t)(h >> (2 * TILE_TIP_BITS));
+                const bool ina = lo_ < a1, inb = hi_ >= a1;  // an inactive entry is {MAX, 0}
+                c_ab += (ina ? w : 0u) | ((inb ? w : 0u) << 16);
+                c_both += (ina && inb) ? w : 0u;
+            }
+            const uint32_t slot = (uint32_t)iteration % 3u;
+            c_ab = wave_sum(c_ab); c_both = wave_sum(c_both);
+            if (lane == 0) { if (c_ab) atomicAdd(&sh.cnt[slot][0], c_ab); if (c_both) atomicAdd(&sh.cnt[slot][1], c_both); }
+            __syncthreads();
+            const uint32_t t_ab = sh.cnt[slot][0];
+            uint32_t cnt_a = t_ab & 0xFFFFu, cnt_b = t_ab >> 16, both = sh.cnt[slot][1];
+            if (tid < 2) sh.cnt[(slot + 2) % 3u][tid] = 0;  // (read by everyone before the barrier just passed; next used two levels on)
+            if (m == 0) cnt_a = 0;                 // no non-LEAF child: nothing is scored (:322-324)
+            if (m < 2) { cnt_b = 0; both = 0; }   // the second child is a LEAF
+            // one_a - rest_a = |only_a| - |only_b| = -(one_b - rest_b) for either remove_intersection: exactly one child
+            // passes `one > rest` when the two differ, none on a tie
+            const uint32_t only_a = cnt_a - both, only_b = cnt_b - both, U = cnt_a + cnt_b - both;
+            const uint64_t pid = ((uint64_t)P.s[5] << 32) | P.s[4];
+            if (only_a == only_b) {
+                if (iteration == 1) record(CLS_UNCLASSIFIABLE_LEVEL1, 0, 0, 1, 0);
+                else record(CLS_MAX_RESOLUTION, 0, 0, (uint32_t)iteration, pid);
+                break;
+            }
+            const bool right = only_b > only_a;
+            P = load_node(db.nodes, fc + (right ? 1u : 0u));
+            if (STATS && tid == 0) ib += 32;
+            if (P.s[3] == 0) {  // no non-LEAF child below the chosen clade (update_introspection_node.rs:45-85)
+                const uint32_t cn = right ? cnt_b : cnt_a, on = right ? only_b : only_a;
+                record(CLS_IDENTITY_FOUND, (int32_t)(rm ? on : cn), (int32_t)(rm ? U - cn : U - on), (uint32_t)iteration, ((uint64_t)P.s[5] << 32) | P.s[4]);
+                break;
+            }
+            // narrow every entry to the chosen clade: one 8-byte split half for an entry with tips on both sides of a1
+            for (uint32_t j = tid; j < n_groups; j += THREADS) {
+                const uint64_t h = hot[j];
+                uint32_t lo_ = (uint32_t)h & TILE_TIP_MASK, hi_ = (uint32_t)(h >> TILE_TIP_BITS) & TILE_TIP_MASK;
+                const uint32_t w = (uint32_t)(h >> (2 * TILE_TIP_BITS));
+                const bool str = lo_ < a1 && hi_ >= a1 && (right || lo_ != a0);
+                bool gone;
+                if (str) {
+                    const uint2 t = ldx<uint2, ADDR32>(half, 2 * xs[j] + (right ? 1u : 0u));
+                    if (STATS) ib += 8;
+                    if (!right) hi_ = t.x; else lo_ = t.x;
+                    xs[j] = t.y;
+                }
+                if (!right) gone = lo_ >= a1 || lo_ == a0;   // no tip strictly below the first child
+                else gone = hi_ < a1 || lo_ == a1;           // nothing in the second child, or it is the tip itself
+                if (gone) { lo_ = TILE_TIP_MASK; hi_ = 0; }
+                if (str || gone) hot[j] = (uint64_t)lo_ | ((uint64_t)hi_ << TILE_TIP_BITS) | ((uint64_t)w << (2 * TILE_TIP_BITS));
+            }
+        }
+        finish_stats();
+    }
+}
+
 // ---- read-length classes ----------------------------------------------------------------------
 // One thread per read: reads are binned by their k-mer count into the kernel wide enough for
 // them (class lists in device memory; nothing returns to the host).  Reads no kernel can hold
 // get their record here.
 constexpr int CLASSIFY_THREADS = 256, CLASSIFY_PER_THREAD = 4;
 __global__ __launch_bounds__(CLASSIFY_THREADS) void classify_kernel(const uint64_t* __restrict__ offsets, uint32_t n_reads, uint32_t k,
-                                                                   uint32_t cap0, uint32_t cap1, uint32_t cap2, uint32_t cap3,
+                                                                   uint32_t cap0, uint32_t cap1, uint32_t cap2, uint32_t cap3, uint32_t cap4,
                                                                    uint32_t* __restrict__ list0, uint32_t* __restrict__ list1,
-                                                                   uint32_t* __restrict__ list2, uint32_t* __restrict__ list3,
+                                                                   uint32_t* __restrict__ list2, uint32_t* __restrict__ list3, uint32_t* __restrict__ list4,
                                                                    uint32_t* __restrict__ counts, cls_placement* __restrict__ out,
                                                                    cls_query_stats* __restrict__ stats) {
     // a workgroup bins 1024 reads: positions inside the workgroup from LDS counters, ONE global atomic per class
-    __shared__ uint32_t s_cnt[4], s_base[4];
-    if (threadIdx.x < 4) s_cnt[threadIdx.x] = 0;
+    __shared__ uint32_t s_cnt[5], s_base[5];
+    if (threadIdx.x < 5) s_cnt[threadIdx.x] = 0;
     __syncthreads();
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t first = blockIdx.x * (CLASSIFY_THREADS * CLASSIFY_PER_THREAD) + threadIdx.x;
@@ -2109,7 +2382,8 @@ __global__ __launch_bounds__(CLASSIFY_THREADS) void classify_kernel(const uint64
             if (nk <= cap0) cls_id[i] = 0;  // includes L < k: the kernel reports CLS_ERR_TOO_FEW_KMERS
             else if (nk <= cap1) cls_id[i] = 1;
             else if (nk <= cap2) cls_id[i] = 2;
-            else if (nk <= cap3) cls_id[i] = 3;  // cap3 = 0: no long-read class in this launch
+            else if (nk <= cap3) cls_id[i] = 3;  // cap3 = 0: no LDS-tiled long-read class in this launch
+            else if (nk <= cap4) cls_id[i] = 4;  // cap4 = 0: no workspace long-read class in this launch
             else {
                 uint64_t* o = reinterpret_cast<uint64_t*>(out + r);
                 o[0] = CLS_ERR_READ_TOO_LONG; o[1] = 0; o[2] = 0;
@@ -2120,7 +2394,7 @@ __global__ __launch_bounds__(CLASSIFY_THREADS) void classify_kernel(const uint64
             }
         }
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
+        for (int c = 0; c < 5; ++c) {
             const uint64_t m = __ballot(cls_id[i] == c);
             if (!m) continue;
             uint32_t base = 0;
@@ -2130,12 +2404,12 @@ __global__ __launch_bounds__(CLASSIFY_THREADS) void classify_kernel(const uint64
         }
     }
     __syncthreads();
-    if (threadIdx.x < 4) s_base[threadIdx.x] = s_cnt[threadIdx.x] ? atomicAdd(&counts[threadIdx.x], s_cnt[threadIdx.x]) : 0u;
+    if (threadIdx.x < 5) s_base[threadIdx.x] = s_cnt[threadIdx.x] ? atomicAdd(&counts[threadIdx.x], s_cnt[threadIdx.x]) : 0u;
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < CLASSIFY_PER_THREAD; ++i) {
         const int c = cls_id[i];
-        if (c >= 0) (c == 0 ? list0 : c == 1 ? list1 : c == 2 ? list2 : list3)[s_base[c] + pos[i]] = first + i * CLASSIFY_THREADS;
+        if (c >= 0) (c == 0 ? list0 : c == 1 ? list1 : c == 2 ? list2 : c == 3 ? list3 : list4)[s_base[c] + pos[i]] = first + i * CLASSIFY_THREADS;
     }
 }
 
@@ -2144,27 +2418,29 @@ __global__ __launch_bounds__(CLASSIFY_THREADS) void classify_kernel(const uint64
 namespace {
 constexpr int N_CLASSES = 2;            // wave-per-read classes; class 2 = one workgroup per read
 constexpr int BLK_WAVES = 8, BLK_SLOTS = 16, BLK_SET_BITS = 14;  // 8192 k-mers per read
-constexpr int ORDER_KEY_BITS_MAX = 32 + DIRECT_TIP_BITS;  // {first tip, record offset}
+constexpr int ORDER_KEY_BITS_MAX = TIER_SHIFT + 20;  // {MinHash, set id}
 int order_key_bits(const DbDev& db) {  // + 1: reads without a key sort last with the all-ones key
-    uint32_t tip_bits = 1;
-    while (tip_bits < 32 && (1u << tip_bits) < db.n_nodes) ++tip_bits;
-    return std::min<int>(64, (int)(tip_bits + db.hdr_bits) + 1);
+    const Tuning& tn = tuning();
+    const int bits = tn.order_mode == 1 ? (int)db.set_bits + 20 : std::max(1, (int)db.set_bits - tn.order_block_shift) + 16;
+    return std::min<int>(64, bits + 1);
 }
 constexpr int CLS_SLOTS[N_CLASSES] = {5, 16};      // k-mers per read: 320 / 1024
 constexpr int CLS_SET_BITS[N_CLASSES] = {9, 11};   // LDS distinct-hit set: 512 / 2048 entries
 
 bool use_fast(const DbDev& db);
 bool use_order(const DbDev& db, uint32_t n_reads) {
-    static const bool off = getenv("CLS_NO_ORDER") != nullptr;  // A/B experiments
-    return use_fast(db) && !off && n_reads >= 4096;
+    return use_fast(db) && !tuning().no_order && n_reads >= 4096;
 }
 bool use_fast(const DbDev& db) {
-    static const bool off = getenv("CLS_NO_FAST") != nullptr;  // A/B experiments
-    // with a direct table (k <= 15), or keyed by MurmurHash3 through the hash table (pre-order indices must fit the entry)
-    const bool front = db.direct != nullptr || (db.ftable != nullptr && db.addr32 && db.k <= 256);
-    return db.format == FMT_SPLIT && (db.binary_tree || db.max_nonleaf_arity <= FAST_MAX_ARITY) && front && !off;
+    // with a direct table (k <= 15), or keyed by MurmurHash3 through the hash table
+    const bool front = db.direct != nullptr || (db.addr32 && db.k <= 256);
+    return db.format == FMT_SPLIT && (db.binary_tree || db.max_nonleaf_arity <= FAST_MAX_ARITY) && front && !tuning().no_fast;
 }
 int fast_mode(const DbDev& db) { return db.direct == nullptr ? 2 : db.canonical ? 1 : 0; }
+// the LDS-tiled long-read kernel: binary FMT_SPLIT index with a direct table, pre-order indices in 24 bits
+bool use_tile(const DbDev& db) {
+    return db.format == FMT_SPLIT && db.binary_tree && db.direct != nullptr && db.n_nodes < TILE_TIP_MASK && !tuning().no_tile;
+}
 uint32_t seq_cap_of(const DbDev& db, int c) { return (2 * (64 * CLS_SLOTS[c] / 2 + db.k) + 15) & ~15u; }
 // fast path: L <= 32*SLOTS + k - 1 ascii bytes (+ padding so that the 16-byte packer can over-read)
 uint32_t ascii_cap_of(const DbDev& db, int c) {
@@ -2233,7 +2509,7 @@ PlacePlan plan_place(const DbDev& db, uint32_t n_reads, uint32_t n_cu, bool stat
     PlacePlan p{};
     // persistent-style grids: exactly the blocks that are resident at once (every wave then strides
     // over its class list); CLS_BLOCKS_PER_CU overrides it for tuning experiments
-    static const int forced = [] { const char* e = getenv("CLS_BLOCKS_PER_CU"); return e ? atoi(e) : 0; }();
+    const int forced = tuning().blocks_per_cu;
     const uint32_t want = (n_reads + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
     uint64_t child_words = 0;
     for (int c = 0; c < N_CLASSES; ++c) {
@@ -2252,9 +2528,9 @@ PlacePlan plan_place(const DbDev& db, uint32_t n_reads, uint32_t n_cu, bool stat
     }
     p.grid_blk = std::max<uint32_t>(1, std::min<uint32_t>(n_reads, n_cu));  // 1 workgroup per CU (LDS-bound)
     if (!child_in_lds(db)) child_words = std::max<uint64_t>(child_words, (uint64_t)p.grid_blk * 2 * child_ws_stride(db));
-    // workspace (u32 words): [counts 16][list0 n][list1 n][list2 n][list3 n][keys_in 2n][keys_out 2n][idx_in n][idx_out n][sort temp][child counters][long-read slices]
+    // workspace (u32 words): [counts 16][list0 n][list1 n][list2 n][list3 n][list4 n][keys_in 2n][keys_out 2n][idx_in n][idx_out n][sort temp][child counters][long-read slices]
     p.ordered = use_order(db, n_reads);
-    uint64_t w = 16 + 4 * (uint64_t)n_reads;
+    uint64_t w = 16 + 5 * (uint64_t)n_reads;
     w += w & 1;
     if (p.ordered) {
         // every resident workgroup (5 per CU at 96 VGPRs): since k-mers share split trees and the descent runs
@@ -2263,8 +2539,7 @@ PlacePlan plan_place(const DbDev& db, uint32_t n_reads, uint32_t n_cu, bool stat
         p.grid[0] = std::max<uint32_t>(8, p.grid[0] & ~7u);  // whole octets of workgroups: one slice of the list per XCD
         p.grid[1] = std::max<uint32_t>(8, p.grid[1] & ~7u);
         {   // the key kernel is bound by the latency of random table reads: every wave the CU can hold
-            static const int forced_key = [] { const char* e = getenv("CLS_KEY_BLOCKS_PER_CU"); return e ? atoi(e) : 0; }();
-            int per_cu = forced_key;
+            int per_cu = tuning().key_blocks_per_cu;
             const uint32_t ac = ascii_cap_of(db, 0);
             const size_t smem_k = (size_t)WAVES_PER_BLOCK * (ac + (db.direct ? 4u * (((ac >> 4) + 2 + 3) & ~3u) : 0u) + 16u);
             const void* kfn = fast_mode(db) == 2 ? (const void*)order_key_kernel<CLS_SLOTS[0], true, true, true>
@@ -2282,6 +2557,26 @@ PlacePlan plan_place(const DbDev& db, uint32_t n_reads, uint32_t n_cu, bool stat
     p.child_off_words = w;
     w += child_words;
     w += w & 1;
+    // LDS-tiled long-read class (binary FMT_SPLIT index with a direct table): as many lookups per read as 160 KB of LDS hold
+    if (long_cap > MAX_READ_KMERS && n_long && use_tile(db)) {
+        const bool canon = db.canonical != 0;
+        const uint32_t want = canon ? long_cap / 2 : long_cap;  // lookups of the longest read (canonical: one per window)
+        auto bases_of = [&](uint32_t look) { return (canon ? look : look / 2) + db.k; };
+        uint32_t look = want;
+        const size_t lds_max = 160 * 1024 - sizeof(TileSh) - 256;
+        if (tile_smem(look, bases_of(look)) > lds_max) {
+            look = (uint32_t)((lds_max - 4ull * TILE_SET_ENTRIES - 64 - 4ull * 8) / 12);
+            while (look > 64 && tile_smem(look, bases_of(look)) > lds_max) look -= 64;
+        }
+        look = std::min<uint32_t>(look, 32767u);  // weights are summed in 16-bit halves
+        p.tile_lookups = look;
+        p.tile_bases = bases_of(look);
+        p.tile_smem = tile_smem(p.tile_lookups, p.tile_bases);
+        const uint32_t per_cu = (uint32_t)std::min<size_t>(2, (160 * 1024) / (p.tile_smem + sizeof(TileSh) + 256));
+        p.tile_threads = per_cu >= 2 ? 512u : 1024u;
+        p.grid_tile = std::max<uint32_t>(1, std::min<uint32_t>(n_long, n_cu * std::max(1u, per_cu)));
+        p.tile_cap_kmers = canon ? 2 * look : look;
+    }
     // long-read class: per workgroup two state buffers (the distinct-hit set shares the second) + child counters
     if (long_cap > MAX_READ_KMERS && n_long) {
         p.long_cap = long_cap;
@@ -2291,8 +2586,9 @@ PlacePlan plan_place(const DbDev& db, uint32_t n_reads, uint32_t n_cu, bool stat
         p.long_stride_words = 2 * (uint64_t)LONG_STATE_WORDS * long_cap + 2 * (uint64_t)p.long_arity;
         const uint64_t fit = std::max<uint64_t>(1, (2ull << 30) / (p.long_stride_words * 4));  // at most 2 GiB of slices
         // the kernel is bound by the latency of dependent reads and uses little LDS / few registers: several reads per CU
-        static const uint64_t per_cu_long = [] { const char* e = getenv("CLS_LONG_BLOCKS_PER_CU"); return e ? (uint64_t)atoi(e) : 2ull; }();  // (1: 25.5 k reads/s of 10 kb, 2..8: 31 k)
+        const uint64_t per_cu_long = (uint64_t)std::max(1, tuning().long_blocks_per_cu);  // (1: 25.5 k reads/s of 10 kb, 2..8: 31 k)
         p.grid_long = (uint32_t)std::min<uint64_t>({(uint64_t)n_long, (uint64_t)n_cu * per_cu_long, fit});
+        if (p.tile_cap_kmers >= long_cap) p.grid_long = std::min<uint32_t>(p.grid_long, 8u);  // only reads the tile kernel spills come here
         p.long_off_words = w;
         w += p.long_stride_words * p.grid_long;
     }
@@ -2305,16 +2601,17 @@ hipError_t launch_place(const DbDev& db, const PlaceParams& prm, const PlacePlan
                         uint32_t* d_ws, hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop) {
     if (n_reads == 0) return hipSuccess;
     uint32_t* counts = d_ws;
-    uint32_t* lists[4] = {d_ws + 16, d_ws + 16 + n_reads, d_ws + 16 + 2 * (size_t)n_reads, d_ws + 16 + 3 * (size_t)n_reads};
+    uint32_t* lists[5] = {d_ws + 16, d_ws + 16 + n_reads, d_ws + 16 + 2 * (size_t)n_reads, d_ws + 16 + 3 * (size_t)n_reads, d_ws + 16 + 4 * (size_t)n_reads};
     uint32_t* child_ws = (child_ws_stride(db) && !child_in_lds(db)) ? d_ws + plan.child_off_words : nullptr;
     hipError_t e = hipMemsetAsync(counts, 0, 64, stream);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(classify_kernel, dim3((n_reads + CLASSIFY_THREADS * CLASSIFY_PER_THREAD - 1) / (CLASSIFY_THREADS * CLASSIFY_PER_THREAD)), dim3(CLASSIFY_THREADS), 0, stream, d_offsets, n_reads, db.k,
-                       (uint32_t)(64 * CLS_SLOTS[0]), (uint32_t)(64 * CLS_SLOTS[1]), (uint32_t)(64 * BLK_WAVES * BLK_SLOTS), plan.long_cap,
-                       lists[0], lists[1], lists[2], lists[3], counts, d_out, d_stats);
+                       (uint32_t)(64 * CLS_SLOTS[0]), (uint32_t)(64 * CLS_SLOTS[1]), (uint32_t)(64 * BLK_WAVES * BLK_SLOTS),
+                       plan.grid_tile ? plan.tile_cap_kmers : 0u, plan.long_cap,
+                       lists[0], lists[1], lists[2], lists[3], lists[4], counts, d_out, d_stats);
     // CLS_PROFILE_STOP=1|2 truncates the split kernel after the match / state-init phase (timing
     // breakdowns only: the records it then writes are meaningless)
-    static const uint32_t profile_stop = [] { const char* e = getenv("CLS_PROFILE_STOP"); return e ? (uint32_t)atoi(e) : 0u; }();
+    const uint32_t profile_stop = (uint32_t)tuning().profile_stop;
     const uint32_t ws_stride = child_ws_stride(db);
     const bool st = d_stats != nullptr;
     const bool binary = db.max_nonleaf_arity <= 2;
@@ -2326,18 +2623,17 @@ hipError_t launch_place(const DbDev& db, const PlaceParams& prm, const PlacePlan
         uint32_t* idx_in = reinterpret_cast<uint32_t*>(keys_out + n_reads);
         uint32_t* idx_out = idx_in + n_reads;
         const uint32_t ac = ascii_cap_of(db, 0);
-        uint32_t tip_bits = 1;
-        while (tip_bits < 32 && (1u << tip_bits) < db.n_nodes) ++tip_bits;
-        static const uint32_t spec_lg = [] { const char* v = getenv("CLS_ORDER_SPEC_LG"); return v ? (uint32_t)atoi(v) : 3u; }();
-        static const uint32_t fwd_only = [] { const char* v = getenv("CLS_ORDER_BOTH_STRANDS"); return v ? 0u : 1u; }();
-        static const uint32_t sample_shift = [] { const char* v = getenv("CLS_ORDER_SAMPLE_SHIFT"); return v ? (uint32_t)atoi(v) : 32u; }();
-        static const uint32_t block_shift = [] { const char* v = getenv("CLS_ORDER_BLOCK_SHIFT"); return v ? (uint32_t)atoi(v) : 2u; }();
+        const Tuning& tn = tuning();
+        const uint32_t key_mode = (uint32_t)tn.order_mode;
+        const uint32_t fwd_only = tn.order_both_strands ? 0u : 1u;
+        const uint32_t sample_shift = (uint32_t)tn.order_sample_shift;
+        const uint32_t block_shift = (uint32_t)tn.order_block_shift;
         const size_t smem_k = (size_t)WAVES_PER_BLOCK * (ac + (db.direct ? 4u * (((ac >> 4) + 2 + 3) & ~3u) : 0u) + 16u);
         // windows of a read that make its key (CLS_ORDER_WINDOWS; 64 = one lookup slot per lane, 160 = all of a 150 bp read)
-        static const uint32_t key_windows = [] { const char* v = getenv("CLS_ORDER_WINDOWS"); return v ? (uint32_t)atoi(v) : 64u; }();
+        const uint32_t key_windows = (uint32_t)tn.order_windows;
 #define CLS_LAUNCH_KEY_S(SL, A32, FW, HS)                                                                                                 \
     hipLaunchKernelGGL((order_key_kernel<SL, A32, FW, HS>), dim3(plan.grid_key), dim3(64 * WAVES_PER_BLOCK), smem_k, stream, db,          \
-                       d_bases, d_offsets, n_reads, keys_in, idx_in, ac, tip_bits, spec_lg, block_shift, sample_shift, fwd_only,          \
+                       d_bases, d_offsets, n_reads, keys_in, idx_in, ac, key_mode, block_shift, sample_shift, fwd_only,                    \
                        (uint32_t)(64 * CLS_SLOTS[1]))
 #define CLS_LAUNCH_KEY(A32, HS)                                                                                                           \
     do {                                                                                                                                  \
@@ -2350,10 +2646,10 @@ hipError_t launch_place(const DbDev& db, const PlaceParams& prm, const PlacePlan
             const uint32_t grid_half = std::max<uint32_t>(1, std::min<uint32_t>((n_reads + 2 * WAVES_PER_BLOCK - 1) / (2 * WAVES_PER_BLOCK), plan.grid_key));
             if (db.addr32)
                 hipLaunchKernelGGL((order_key_half_kernel<true>), dim3(grid_half), dim3(64 * WAVES_PER_BLOCK), 0, stream, db, d_bases, d_offsets,
-                                   n_reads, keys_in, idx_in, tip_bits, spec_lg, block_shift, (uint32_t)(64 * CLS_SLOTS[1]));
+                                   n_reads, keys_in, idx_in, key_mode, block_shift, (uint32_t)(64 * CLS_SLOTS[1]));
             else
                 hipLaunchKernelGGL((order_key_half_kernel<false>), dim3(grid_half), dim3(64 * WAVES_PER_BLOCK), 0, stream, db, d_bases, d_offsets,
-                                   n_reads, keys_in, idx_in, tip_bits, spec_lg, block_shift, (uint32_t)(64 * CLS_SLOTS[1]));
+                                   n_reads, keys_in, idx_in, key_mode, block_shift, (uint32_t)(64 * CLS_SLOTS[1]));
         }
         else if (fast_mode(db) == 2) CLS_LAUNCH_KEY(true, true);
         else if (db.addr32) CLS_LAUNCH_KEY(true, false);
@@ -2427,12 +2723,30 @@ hipError_t launch_place(const DbDev& db, const PlaceParams& prm, const PlacePlan
         else { if (st) CLS_LAUNCH_BLK(true, false, false); else CLS_LAUNCH_BLK(false, false, false); }
 #undef CLS_LAUNCH_BLK
     }
-    if (plan.grid_long) {  // class 3: reads beyond the register-resident kernels, state in the workspace
+    if (plan.grid_tile) {  // class 3: long reads, every state in LDS; reads it cannot hold are appended to class 4's list
+        if (hipGetLastError() != hipSuccess) return hipErrorLaunchFailure;
+#define CLS_LAUNCH_TILE(TH, CN, ST, A32)                                                                                          \
+    do {                                                                                                                          \
+        auto kfn = place_tile_kernel<TH, CN, ST, A32>;                                                                            \
+        (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)plan.tile_smem);             \
+        hipLaunchKernelGGL(kfn, dim3(plan.grid_tile), dim3(TH), plan.tile_smem, stream, db, prm, d_bases, d_offsets, lists[3],    \
+                           counts + 3, d_out, d_stats, plan.tile_lookups, plan.tile_bases,                                       \
+                           (uint32_t)std::max(1, tuning().tile_pass_codes), lists[4], counts + 4);                                \
+    } while (0)
+#define CLS_LAUNCH_TILE3(TH, CN, ST) do { if (db.addr32) CLS_LAUNCH_TILE(TH, CN, ST, true); else CLS_LAUNCH_TILE(TH, CN, ST, false); } while (0)
+#define CLS_LAUNCH_TILE2(TH, CN) do { if (st) CLS_LAUNCH_TILE3(TH, CN, true); else CLS_LAUNCH_TILE3(TH, CN, false); } while (0)
+        if (plan.tile_threads == 512) { if (db.canonical) CLS_LAUNCH_TILE2(512, true); else CLS_LAUNCH_TILE2(512, false); }
+        else { if (db.canonical) CLS_LAUNCH_TILE2(1024, true); else CLS_LAUNCH_TILE2(1024, false); }
+#undef CLS_LAUNCH_TILE2
+#undef CLS_LAUNCH_TILE3
+#undef CLS_LAUNCH_TILE
+    }
+    if (plan.grid_long) {  // class 4: reads beyond what the LDS holds (and every long read of the other index shapes): state in the workspace
         if (hipGetLastError() != hipSuccess) return hipErrorLaunchFailure;
         uint32_t* lws = d_ws + plan.long_off_words;
 #define CLS_LAUNCH_LONG(SP, ST)                                                                                                 \
     hipLaunchKernelGGL((place_long_kernel<SP, ST>), dim3(plan.grid_long), dim3(LONG_THREADS), 0, stream, db, prm, d_bases, d_offsets, \
-                       lists[3], counts + 3, d_out, d_stats, lws, plan.long_stride_words, plan.long_cap, (uint32_t)plan.long_set,  \
+                       lists[4], counts + 4, d_out, d_stats, lws, plan.long_stride_words, plan.long_cap, (uint32_t)plan.long_set,  \
                        plan.long_arity)
         if (db.format == FMT_SPLIT) { if (st) CLS_LAUNCH_LONG(true, true); else CLS_LAUNCH_LONG(true, false); }
         else { if (st) CLS_LAUNCH_LONG(false, true); else CLS_LAUNCH_LONG(false, false); }

@@ -269,6 +269,26 @@ extern "C" int cls_synth_db_create(const cls_synth_cfg* cfg, cls_synth_db** out)
         std::vector<uint32_t> parent_row(NN);
         for (uint32_t r = 0; r < NN; ++r) parent_row[r] = T[row2node[r]].parent < 0 ? UINT32_MAX : (uint32_t)row[T[row2node[r]].parent];
         for (int pass = 0; pass < 2; ++pass) {
+            if (cfg->tips_only) {  // only the distinct leaves of every k-mer: the node set is the union of their root paths
+#pragma omp parallel for num_threads(threads) schedule(dynamic, 4096)
+                for (size_t g = 0; g < G; ++g) {
+                    uint64_t cnt = 0;
+                    uint64_t* dst = pass ? &S->node_ids[S->kmer_node_off[g]] : nullptr;
+                    uint32_t prev = UINT32_MAX;
+                    for (size_t i = grps[g].lo; i < grps[g].hi; ++i) {  // (sorted by leaf inside a group)
+                        if (recs[i].leaf == prev) continue;
+                        prev = recs[i].leaf;
+                        if (pass) dst[cnt] = S->nodes[S->leaf_row[prev]].id;
+                        ++cnt;
+                    }
+                    if (!pass) S->kmer_node_off[g + 1] = cnt;
+                }
+                if (!pass) {
+                    for (size_t g = 0; g < G; ++g) S->kmer_node_off[g + 1] += S->kmer_node_off[g];
+                    S->node_ids.resize(S->kmer_node_off[G]);
+                }
+                continue;
+            }
 #pragma omp parallel num_threads(threads)
             {
                 std::vector<uint64_t> stamp(NN, 0);
@@ -308,6 +328,7 @@ extern "C" int cls_synth_db_create(const cls_synth_cfg* cfg, cls_synth_db** out)
         d.kmer_hash = S->kmer_hash.data();
         d.kmer_node_off = S->kmer_node_off.data();
         d.node_ids = S->node_ids.data();
+        d.node_set_kind = cfg->tips_only ? CLS_SETS_LEAVES : CLS_SETS_EXPLICIT;
         *out = S;
         return CLS_OK;
     } catch (const std::exception& e) {

@@ -35,7 +35,9 @@ typedef struct cls_synth_cfg {
     uint64_t id_stride;      /* clade id = id_offset + id_stride * preorder (1)  */
     uint64_t id_offset;      /* (0); the root keeps id_offset                    */
     uint32_t threads;        /* 0 = all cores                                    */
-    uint32_t pad_;
+    uint32_t tips_only;      /* 1: the view lists only the LEAF ids of every node set (CLS_SETS_LEAVES): the explicit
+                              * sets of a deep tree (config 5: 50 k leaves at depth 900) would be terabytes and are
+                              * never materialised                                */
 } cls_synth_cfg;
 
 typedef struct cls_synth_db cls_synth_db; /* owns every array `desc` points at */

@@ -1,0 +1,29 @@
+// Experiment knobs of the library, in one place.  None changes a result.  The product never reads the environment
+// on its own: a host sets a knob through cls_set_tuning() (include/cls_place.h), and tools/ + bench.py may call
+// cls_tuning_from_env() once to take them from CLS_* variables (A/B runs on the GPU box).
+#pragma once
+
+namespace cls {
+
+struct Tuning {
+    int no_fast = 0;              // CLS_NO_FAST: generic kernels only
+    int no_order = 0;             // CLS_NO_ORDER: no locality order
+    int force_list = 0;           // CLS_FORCE_LIST: sorted-list postings even when every node set is closed
+    int no_tile = 0;              // CLS_NO_TILE: long reads through the workspace kernel only
+    int tile_pass_codes = 1536;   // CLS_TILE_PASS_CODES: lookups per pass of the LDS-tiled kernel's 4096-entry code set (a huge
+                                  // value forces one pass, so that long reads overflow the set and take the spill path: tests)
+    int blocks_per_cu = 0;        // CLS_BLOCKS_PER_CU: grid of the wave-per-read kernels (0: what is resident)
+    int key_blocks_per_cu = 0;    // CLS_KEY_BLOCKS_PER_CU
+    int long_blocks_per_cu = 2;   // CLS_LONG_BLOCKS_PER_CU: workspace long-read kernel
+    int order_mode = 0;           // CLS_ORDER_MODE: 0 = {leaf neighbourhood, MinHash}, 1 = {MinHash of all k-mers, leaf neighbourhood}
+    int order_windows = 64;       // CLS_ORDER_WINDOWS: windows of a read that make its locality key
+    int order_both_strands = 0;   // CLS_ORDER_BOTH_STRANDS
+    int order_block_shift = 2;    // CLS_ORDER_BLOCK_SHIFT
+    int order_sample_shift = 32;  // CLS_ORDER_SAMPLE_SHIFT
+    int profile_stop = 0;         // CLS_PROFILE_STOP (needs a -DCLS_PROFILE_HOOKS build)
+    int timing = 0;               // CLS_TIMING: phase times of cls_place_sequences on stderr
+};
+
+Tuning& tuning();
+
+}  // namespace cls

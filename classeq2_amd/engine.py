@@ -25,7 +25,7 @@ EXPORTS = [
     "cls_db_set_max_read_len", "cls_place_batch",
     "cls_place_batch_device", "cls_place_batch_stats", "cls_fasta_parse", "cls_fasta_free", "cls_fasta_scan_device", "cls_fasta_dev_free",
     "cls_fasta_parse_gpu", "cls_place_fasta_text", "cls_last_error",
-    "cls_version",
+    "cls_version", "cls_set_tuning", "cls_tuning_from_env",
 ]
 HOST_EXPORTS = [
     "cls_tree_load_json", "cls_tree_load", "cls_tree_init_from_file", "cls_tree_from_newick", "cls_tree_serialize", "cls_tree_save", "cls_tree_free", "cls_tree_set_annotations_yaml", "cls_tree_build_kmers_map", "cls_tree_desc", "cls_serialize_results",
@@ -87,6 +87,10 @@ def lib():
         L.cls_fasta_free.restype = None
         L.cls_last_error.restype = C.c_char_p
         L.cls_version.restype = C.c_char_p
+        L.cls_set_tuning.argtypes = [C.c_char_p, i32]
+        L.cls_set_tuning.restype = i32
+        L.cls_tuning_from_env.argtypes = []
+        L.cls_tuning_from_env.restype = None
         # host-side mirror (include/cls_host.h)
         L.cls_tree_load_json.argtypes = [C.c_char_p, C.POINTER(vp)]
         L.cls_tree_load_json.restype = i32
@@ -155,6 +159,16 @@ def make_params(max_iterations: Optional[int] = None, min_match_coverage: Option
         p.flags |= _abi.HAS_REMOVE_INTERSECTION
         p.remove_intersection = 1 if remove_intersection else 0
     return p
+
+
+def set_tuning(name: str, value: int) -> None:
+    """An experiment knob of the library (csrc/cls_tuning.h); none changes a result."""
+    _check(lib().cls_set_tuning(name.encode(), int(value)))
+
+
+def tuning_from_env() -> None:
+    """Take every knob from its CLS_* environment variable (tools/ and A/B runs; the library never does on its own)."""
+    lib().cls_tuning_from_env()
 
 
 def device_count() -> int:

@@ -29,6 +29,7 @@ class FlatDb:
     kmer_node_off: np.ndarray  # u64 [n_kmers+1]
     node_ids: np.ndarray  # u64 [kmer_node_off[-1]]
     _keepalive: object = None
+    leaves_only: bool = False  # node_ids list only the LEAF-kind members (CLS_SETS_LEAVES, include/cls_place.h)
 
     def __post_init__(self):
         self.nodes = np.ascontiguousarray(self.nodes, dtype=_abi.NODE_DTYPE)
@@ -59,6 +60,7 @@ class FlatDb:
         d.kmer_hash = self.kmer_hash.ctypes.data_as(u64p)
         d.kmer_node_off = self.kmer_node_off.ctypes.data_as(u64p)
         d.node_ids = self.node_ids.ctypes.data_as(u64p)
+        d.node_set_kind = _abi.SETS_LEAVES if self.leaves_only else _abi.SETS_EXPLICIT
         return d
 
     @classmethod
@@ -83,7 +85,45 @@ class FlatDb:
             kmer_node_off=kmer_node_off,
             node_ids=arr(d.node_ids, int(kmer_node_off[-1]) if nk else 0, np.uint64),
             _keepalive=None if copy else keepalive,
+            leaves_only=bool(d.abi_version >= 2 and d.node_set_kind == _abi.SETS_LEAVES),
         )
+
+    def to_leaves_only(self) -> "FlatDb":
+        """The same index with every node set reduced to its LEAF-kind members (what CLS_SETS_LEAVES carries); only
+        equivalent when the sets are unions of root->leaf paths, as `cls build-db` makes them."""
+        leaf_ids = np.sort(self.nodes["id"][self.nodes["kind"] == _abi.KIND_LEAF])
+        pos = np.searchsorted(leaf_ids, self.node_ids)
+        keep = (pos < len(leaf_ids)) & (leaf_ids[np.minimum(pos, len(leaf_ids) - 1)] == self.node_ids)
+        csum = np.concatenate([[0], np.cumsum(keep)])
+        return FlatDb(nodes=self.nodes.copy(), k_size=self.k_size, m_size=self.m_size, bucket_key=self.bucket_key.copy(),
+                      bucket_kmer_off=self.bucket_kmer_off.copy(), kmer_hash=self.kmer_hash.copy(),
+                      kmer_node_off=csum[self.kmer_node_off.astype(np.int64)].astype(np.uint64), node_ids=self.node_ids[keep],
+                      leaves_only=True)
+
+    def to_explicit(self) -> "FlatDb":
+        """A leaves-only index expanded to explicit node sets (union of the root->leaf paths): what the reference's own
+        index file holds, and what the oracle is fed."""
+        assert self.leaves_only
+        ids = self.nodes["id"]
+        order = np.argsort(ids)
+        row_of = lambda x: order[np.searchsorted(ids[order], x)]  # noqa: E731
+        parent_row = np.full(len(ids), -1, dtype=np.int64)
+        has_par = self.nodes["parent"] != _abi.NO_PARENT
+        parent_row[has_par] = row_of(self.nodes["parent"][has_par])
+        off = self.kmer_node_off.astype(np.int64)
+        out_ids, out_off = [], [0]
+        for j in range(len(off) - 1):
+            seen = set()
+            for r in row_of(self.node_ids[off[j]:off[j + 1]]):
+                r = int(r)
+                while r >= 0 and r not in seen:
+                    seen.add(r)
+                    r = int(parent_row[r])
+            out_ids.extend(int(ids[r]) for r in seen)
+            out_off.append(len(out_ids))
+        return FlatDb(nodes=self.nodes.copy(), k_size=self.k_size, m_size=self.m_size, bucket_key=self.bucket_key.copy(),
+                      bucket_kmer_off=self.bucket_kmer_off.copy(), kmer_hash=self.kmer_hash.copy(),
+                      kmer_node_off=np.array(out_off, dtype=np.uint64), node_ids=np.array(out_ids, dtype=np.uint64))
 
     @classmethod
     def from_nested(cls, root: dict, k_size: int, m_size: int, kmers_map: dict) -> "FlatDb":

@@ -68,11 +68,12 @@ class SynthDb:
     """Owns one generated tree + reference sequences + k-mer index."""
 
     def __init__(self, n_leaves, ref_len, k_size, m_size=4, seed_tree=1, seed_refseq=2, edge_sub_rate=0.01,
-                 deep=0, max_depth=0, collapse_prob=0.0, id_stride=1, id_offset=0, threads=0, **_ignored):
+                 deep=0, max_depth=0, collapse_prob=0.0, id_stride=1, id_offset=0, threads=0, tips_only=False, **_ignored):
         cfg = _abi.SynthCfg(
             n_leaves=n_leaves, ref_len=ref_len, k_size=k_size, m_size=m_size, seed_tree=seed_tree,
             seed_refseq=seed_refseq, edge_sub_rate=edge_sub_rate, deep=deep, max_depth=max_depth,
             collapse_prob=collapse_prob, id_stride=id_stride, id_offset=id_offset, threads=threads,
+            tips_only=1 if tips_only else 0,
         )
         self.cfg = cfg
         self._h = C.c_void_p()

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define CLS_ABI_VERSION 1u
+#define CLS_ABI_VERSION 2u  /* 1 is still accepted: cls_db_desc without the trailing node_set_kind */
 
 /* ---- error codes ------------------------------------------------------- */
 #define CLS_OK 0
@@ -81,7 +81,22 @@ typedef struct cls_db_desc {
     const uint64_t* kmer_hash;        /* [n_kmers]     murmur3_x64_128(kmer,0).0 */
     const uint64_t* kmer_node_off;    /* [n_kmers+1]                             */
     const uint64_t* node_ids;         /* [kmer_node_off[n_kmers]] clade ids      */
+    /* abi_version >= 2 */
+    uint32_t node_set_kind;           /* CLS_SETS_*                              */
+    uint32_t pad_;
 } cls_db_desc;
+
+/* What `node_ids` lists per k-mer:
+ * CLS_SETS_EXPLICIT  every member of the node set, as the reference's index file holds it
+ *                    (MinimizerValue: HashSet<u64> of clade ids, kmers_map.rs:16-17);
+ * CLS_SETS_LEAVES    only the LEAF-kind members.  `map_kmers_to_tree` builds every node set as a union of
+ *                    root->leaf paths (build_database/mod.rs:160-169; `get_path_to_root`, clade.rs:127-156), so the
+ *                    leaves determine it: node set := union over the listed leaves of {leaf, its ancestors, root}.
+ *                    The explicit sets of a deep tree are depth times larger (50 k leaves at depth 900: terabytes);
+ *                    this form is what a caller derives from them (filter by kind) or builds directly.  Every id
+ *                    must be a childless LEAF-kind clade of the tree (else CLS_E_BAD_DB). */
+#define CLS_SETS_EXPLICIT 0u
+#define CLS_SETS_LEAVES 1u
 
 /* ---- per-call parameters: the three Option<> arguments ------------------ */
 #define CLS_HAS_MAX_ITERATIONS 1u      /* Some(max_iterations); else 1000        */
@@ -266,6 +281,13 @@ int cls_fasta_parse_gpu(const char* text, size_t len, int device, cls_fasta* out
  * Replaces mod.rs:108-159 (reader thread + channel + per-query place_sequence). */
 int cls_place_fasta_text(cls_db* db, const char* text, size_t len, const cls_params* params, cls_fasta* fa,
                          cls_placement** records);
+
+/* Experiment knobs (grid sizes, locality-key definition, kernel family; none changes a result; names in
+ * csrc/cls_tuning.h are the CLS_* variables in lower case without the prefix, e.g. "no_order").  Process-global,
+ * meant for A/B runs: the library itself never reads the environment.  cls_tuning_from_env() takes every knob
+ * from its CLS_* variable, once, when a tool asks for it.  Set knobs before creating handles. */
+int cls_set_tuning(const char* name, int value);
+void cls_tuning_from_env(void);
 
 /* Thread-local message of the last failing call on this thread ("" if none). */
 const char* cls_last_error(void);

@@ -100,6 +100,12 @@ struct cls_oracle {
     uint64_t* bucket_off;   /* [n_buckets+1] k-mer ranges of the buckets (descriptor order) */
     uint64_t* kmer_hash;    /* hashes in descriptor order                       */
     int reference_cost;     /* also pay the reference's per-query overheads (cls_oracle_set_reference_cost) */
+    /* CLS_SETS_LEAVES input (deep trees, whose explicit sets do not fit any memory): the node set of a k-mer is the
+     * union of the root->leaf paths of its listed leaves (build_database/mod.rs:160-169), kept LAZILY: a clade is a
+     * member iff a listed leaf lies in its subtree.  `nodes_sorted` then holds the leaves' DFS entry times and
+     * tin/tout the entry / exit time of every row.  tests/test_oracle.py holds this mode to the explicit one. */
+    int leaves_only;
+    uint32_t *tin, *tout;
 };
 typedef struct cls_oracle cls_oracle;
 
@@ -121,8 +127,22 @@ static int set_contains(const uint64_t* s, uint64_t n, uint64_t v) {
     return lo < n && s[lo] == v;
 }
 
+/* is the clade of row `row` in the node set of k-mer j?  (HashSet<u64>::contains, kmers_map.rs:44-46, :220) */
+static int kmer_has_node(const struct cls_oracle* o, uint64_t j, uint32_t row) {
+    const uint64_t* s = o->nodes_sorted + o->node_off[j];
+    const uint64_t n = o->node_off[j + 1] - o->node_off[j];
+    if (!o->leaves_only) return set_contains(s, n, o->nodes[row].id);
+    uint64_t lo = 0, hi = n;  /* first listed leaf entered at or after `row` ... */
+    while (lo < hi) {
+        uint64_t mid = (lo + hi) / 2;
+        if (s[mid] < o->tin[row]) lo = mid + 1; else hi = mid;
+    }
+    return lo < n && s[lo] < o->tout[row];  /* ... and before `row` is left: it is below (or is) `row` */
+}
+
 void cls_oracle_destroy(cls_oracle* o) {
     if (!o) return;
+    free(o->tin); free(o->tout);
     free(o->nodes); free(o->bucket_key); free(o->by_hash); free(o->node_off);
     free(o->nodes_sorted); free(o->n_leaf_ids); free(o->bucket_off); free(o->kmer_hash); free(o);
 }
@@ -131,6 +151,7 @@ int cls_oracle_create(const cls_db_desc* d, cls_oracle** out) {
     if (!d || !out || d->n_nodes == 0 || d->k_size == 0) return CLS_E_INVALID_ARG;
     cls_oracle* o = calloc(1, sizeof *o);
     if (!o) return CLS_E_NOMEM;
+    o->leaves_only = d->abi_version >= 2 && d->node_set_kind == CLS_SETS_LEAVES;
     o->n_nodes = d->n_nodes; o->k = d->k_size; o->m = d->m_size;
     o->n_buckets = d->n_buckets; o->n_kmers = d->n_kmers;
     uint64_t tot = d->n_kmers ? d->kmer_node_off[d->n_kmers] : 0;
@@ -155,6 +176,29 @@ int cls_oracle_create(const cls_db_desc* d, cls_oracle** out) {
     uint64_t n_leaf = 0;
     for (uint32_t r = 0; r < d->n_nodes; r++) if (d->nodes[r].kind == CLS_KIND_LEAF) leaf_ids[n_leaf++] = d->nodes[r].id;
     qsort(leaf_ids, n_leaf, 8, cmp_u64);
+    /* leaves-only input: DFS entry / exit times of every row, and id -> row for the listed ids */
+    uint64_t* id_row = NULL; /* (id, row) pairs sorted by id */
+    if (o->leaves_only) {
+        o->tin = malloc(4 * (size_t)d->n_nodes); o->tout = malloc(4 * (size_t)d->n_nodes);
+        uint32_t* stack = malloc(8 * (size_t)d->n_nodes + 8);
+        id_row = malloc(16 * (size_t)d->n_nodes);
+        if (!o->tin || !o->tout || !stack || !id_row) { free(stack); free(id_row); free(leaf_ids); cls_oracle_destroy(o); return CLS_E_NOMEM; }
+        uint32_t sp = 0, t = 0;
+        stack[sp++] = 0; stack[sp++] = 0; /* (row, next child) */
+        o->tin[0] = t++;
+        while (sp) {
+            uint32_t row = stack[sp - 2], next = stack[sp - 1];
+            if (next < d->nodes[row].n_children) {
+                stack[sp - 1] = next + 1;
+                uint32_t c = d->nodes[row].first_child + next;
+                o->tin[c] = t++;
+                stack[sp++] = c; stack[sp++] = 0;
+            } else { o->tout[row] = t; sp -= 2; }
+        }
+        free(stack);
+        for (uint32_t r = 0; r < d->n_nodes; r++) { id_row[2 * r] = d->nodes[r].id; id_row[2 * r + 1] = r; }
+        qsort(id_row, d->n_nodes, 16, cmp_u64);
+    }
     uint64_t w = 0;
     for (uint64_t b = 0; b < d->n_buckets; b++)
         for (uint64_t j = d->bucket_kmer_off[b]; j < d->bucket_kmer_off[b + 1]; j++) {
@@ -165,6 +209,21 @@ int cls_oracle_create(const cls_db_desc* d, cls_oracle** out) {
     for (uint64_t j = 0; j < d->n_kmers; j++) {
         uint64_t lo = d->kmer_node_off[j], hi = d->kmer_node_off[j + 1], start = w;
         o->node_off[j] = w;
+        if (o->leaves_only) { /* the listed leaves, as DFS entry times */
+            for (uint64_t i = lo; i < hi; i++) {
+                uint64_t a = 0, b = d->n_nodes, id = d->node_ids[i];
+                while (a < b) { uint64_t mid = (a + b) / 2; if (id_row[2 * mid] < id) a = mid + 1; else b = mid; }
+                if (a >= d->n_nodes || id_row[2 * a] != id || d->nodes[id_row[2 * a + 1]].kind != CLS_KIND_LEAF) {
+                    free(id_row); free(leaf_ids); cls_oracle_destroy(o); return CLS_E_BAD_DB;
+                }
+                o->nodes_sorted[w + (i - lo)] = o->tin[id_row[2 * a + 1]];
+            }
+            qsort(o->nodes_sorted + w, hi - lo, 8, cmp_u64);
+            for (uint64_t i = 0; i < hi - lo; i++)
+                if (i == 0 || o->nodes_sorted[start + i] != o->nodes_sorted[start + i - 1]) o->nodes_sorted[w++] = o->nodes_sorted[start + i];
+            o->n_leaf_ids[j] = (uint32_t)(w - start);
+            continue;
+        }
         memcpy(o->nodes_sorted + w, d->node_ids + lo, 8 * (hi - lo));
         qsort(o->nodes_sorted + w, hi - lo, 8, cmp_u64);
         for (uint64_t i = 0; i < hi - lo; i++) /* a set: drop duplicates */
@@ -173,6 +232,7 @@ int cls_oracle_create(const cls_db_desc* d, cls_oracle** out) {
     }
     o->node_off[d->n_kmers] = w;
     free(leaf_ids);
+    free(id_row);
     qsort(o->by_hash, d->n_kmers, sizeof(hent), cmp_hent);
     *out = o;
     return CLS_OK;
@@ -248,7 +308,6 @@ static void place_one(const cls_oracle* o, const char* seq, uint64_t L, int32_t 
     /* M = { (bucket, hash) : bucket.key in minimizers, hash in hashes }; keep M_root members */
     uint64_t* ent_kmer = S->ent_kmer.p; uint32_t* ent_hidx = S->ent_hidx.p;
     uint64_t n_m = 0, n_root = 0, leaf_post = 0, n_hidx = 0;
-    const uint64_t root_id = o->nodes[0].id;
     for (size_t hi = 0; hi < nh; hi++) {
         uint64_t h = hashes[hi], lo = 0, up = o->n_kmers;
         while (lo < up) { uint64_t mid = (lo + up) / 2; if (o->by_hash[mid].hash < h) lo = mid + 1; else up = mid; }
@@ -259,7 +318,7 @@ static void place_one(const cls_oracle* o, const char* seq, uint64_t L, int32_t 
             n_m++;
             leaf_post += o->n_leaf_ids[j];
             /* get_minimized_hashes_with_node(root.id), kmers_map.rs:211-229 */
-            if (set_contains(o->nodes_sorted + o->node_off[j], o->node_off[j + 1] - o->node_off[j], root_id)) {
+            if (kmer_has_node(o, j, 0)) {
                 ent_kmer = ensure(&S->ent_kmer, n_root + 1, 8); ent_hidx = ensure(&S->ent_hidx, n_root + 1, 4);
                 ent_kmer[n_root] = j; ent_hidx[n_root] = (uint32_t)n_hidx; n_root++; any_root = 1;
             }
@@ -297,7 +356,7 @@ static void place_one(const cls_oracle* o, const char* seq, uint64_t L, int32_t 
             int any = 0;
             for (uint64_t e = 0; e < n_root; e++) { /* full rescan per child, kmers_map.rs:37-53 */
                 uint64_t j = ent_kmer[e];
-                if (set_contains(o->nodes_sorted + o->node_off[j], o->node_off[j + 1] - o->node_off[j], c->id)) {
+                if (kmer_has_node(o, j, child_rows[ci])) {
                     set[ent_hidx[e] >> 6] |= 1ULL << (ent_hidx[e] & 63); any = 1;
                 }
             }
@@ -359,6 +418,7 @@ static void place_one(const cls_oracle* o, const char* seq, uint64_t L, int32_t 
  *        touched bucket into a fresh HashSet before intersecting with the query's hashes. */
 static uint64_t refcost_overhead(const cls_oracle* o, const char* seq, uint64_t L) {
     uint64_t sink = 0;
+    if (o->leaves_only) return 0; /* the explicit sets this mode would clone are never materialised */
     void** sets = malloc(sizeof(void*) * (o->n_kmers + 1));
     void** maps = malloc(sizeof(void*) * (o->n_buckets + 1));
     if (!sets || !maps) { free(sets); free(maps); return 0; }

@@ -303,3 +303,50 @@ def test_c2_shape_parity_sample():
     s = SynthDb(1000, 1500, 8, 4)
     bases, offsets, _ = s.reads(20000, 150)
     _check(s.flat, bases, offsets, {}, threads=16)
+
+
+@pytest.mark.parametrize("case", [(80, 300, 10, 4, 0.0, 0), (100, 300, 12, 4, 0.4, 0), (150, 400, 15, 4, 0.0, 1), (60, 300, 17, 4, 0.2, 0)])
+def test_leaves_only_index_input(case):
+    """cls_db_desc v2, CLS_SETS_LEAVES: the index lists only the LEAF members of every node set (the union of their
+    root paths is implied, build_database/mod.rs:160-169).  Same placements and counters as the explicit index, which
+    is what the oracle -- like the reference -- is fed."""
+    nl, rl, k, m, cp, deep = case
+    s = SynthDb(nl, rl, k, m, collapse_prob=cp, deep=deep)
+    t = SynthDb(nl, rl, k, m, collapse_prob=cp, deep=deep, tips_only=True)
+    assert t.flat.leaves_only and t.flat.node_ids.size < s.flat.node_ids.size
+    bases, offsets, _ = s.reads(1500, min(rl, 150), frac_random=0.05, err=0.02)
+    for kw in PARAM_SETS[:3]:
+        want, wst = op.OraclePort(s.flat).place_batch(bases, offsets, op.make_params(**kw), threads=8, want_stats=True)
+        for flat in (t.flat, s.flat.to_leaves_only()):
+            with engine.PlacementDb(flat, device=0) as db:
+                got, gst = db.place_batch(bases, offsets, engine.make_params(**kw), want_stats=True)
+            assert len(records_equal(got, want)) == 0 and len(stats_equal(gst, wst)) == 0
+    with engine.PlacementDb(t.flat, device=0) as a, engine.PlacementDb(s.flat, device=0) as b:
+        assert (a.info.format, a.info.n_tip_sets, a.info.n_kmers, a.info.direct_table) == (b.info.format, b.info.n_tip_sets, b.info.n_kmers, b.info.direct_table)
+
+
+def test_long_reads_lds_tiled_kernel_and_its_spill_path():
+    """10 kb reads on a binary tree with a direct table (the shape of BASELINE config 5) take the LDS-tiled kernel:
+    strand-symmetric and not, both entries.  With the code set forced into ONE pass a 10 kb read overflows it and is
+    handed to the workspace kernel through the spill list: same records."""
+    s = SynthDb(200, 11000, 15, 4, deep=1)
+    rng = np.random.default_rng(44)
+    bases, offsets = ragged_reads(rng, s, 60, 4200, 10800, lower_frac=0.05)
+    want = {}
+    for flat, tag in ((s.flat, "sym"), (truncate_random_sets(s.flat, 0.02, seed=3), "asym")):
+        for kw in (dict(), dict(remove_intersection=True), dict(max_iterations=7)):
+            got = _check(flat, bases, offsets, kw, threads=16)
+            want[(tag, tuple(kw))] = got
+        assert (got["status"] != _abi.ERR_READ_TOO_LONG).all()
+    engine.set_tuning("tile_pass_codes", 1 << 30)
+    try:
+        got = _check(s.flat, bases, offsets, {}, threads=16)
+        assert len(records_equal(got, want[("sym", ())])) == 0
+    finally:
+        engine.set_tuning("tile_pass_codes", 1536)
+    engine.set_tuning("no_tile", 1)
+    try:
+        got = _check(s.flat, bases, offsets, {}, threads=16)
+        assert len(records_equal(got, want[("sym", ())])) == 0
+    finally:
+        engine.set_tuning("no_tile", 0)

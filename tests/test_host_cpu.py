@@ -30,7 +30,7 @@ def test_header_symbols_exported():
 def test_struct_layouts_match_header():
     assert C.sizeof(_abi.Node) == 32 and C.sizeof(_abi.Placement) == 24 and C.sizeof(_abi.QueryStats) == 24
     assert _abi.Placement.clade_id.offset == 16 and _abi.Placement.levels.offset == 12
-    assert C.sizeof(_abi.DbDesc) == 88
+    assert C.sizeof(_abi.DbDesc) == 96 and _abi.DbDesc.node_set_kind.offset == 88
 
 
 def test_validate_accepts_generated_dbs():
@@ -110,3 +110,30 @@ def test_fasta_parse_matches_literal(txt):
         assert got == [w for w in want][: len(got)] and truncated
         return
     assert got == lit.sequence_content_by_channel(text)
+
+
+def test_leaves_only_descriptor_validation():
+    """cls_db_desc v2 (CLS_SETS_LEAVES): accepted for generated and derived indexes; an id that is not a LEAF clade of
+    the tree is refused; a v1 descriptor (no node_set_kind) still validates."""
+    s = SynthDb(60, 300, 9, 4, collapse_prob=0.3)
+    t = SynthDb(60, 300, 9, 4, collapse_prob=0.3, tips_only=True)
+    engine.validate(t.flat)
+    engine.validate(s.flat.to_leaves_only())
+    f = FlatDb.from_desc(t.flat.desc(), copy=True)
+    assert f.leaves_only
+    internal = int(f.nodes["id"][f.nodes["kind"] == _abi.KIND_NODE][0])
+    f.node_ids[3] = internal
+    with pytest.raises(engine.ClsError, match="LEAF"):
+        engine.validate(f)
+    f = FlatDb.from_desc(t.flat.desc(), copy=True)
+    f.node_ids[0] = 2**63 + 12345  # no clade of the tree at all
+    with pytest.raises(engine.ClsError, match="LEAF"):
+        engine.validate(f)
+    d = s.flat.desc()
+    d.abi_version = 1
+    d.node_set_kind = 77  # ignored by a v1 caller's layout
+    assert engine.lib().cls_db_validate(C.byref(d)) == 0
+    d.abi_version = 2
+    assert engine.lib().cls_db_validate(C.byref(d)) != 0
+    d.abi_version = 3
+    assert engine.lib().cls_db_validate(C.byref(d)) != 0

@@ -134,3 +134,33 @@ def test_fasta_literal_semantics():
     recs = lit.sequence_content_by_channel(txt)
     assert recs == [("a bc", "ACGTACGT"), ("second", ""), ("third", ""), ("z", "GG")]
     assert lit.sequence_content_by_channel("ACGT\n>h\nAC\n") == []  # sequence before any header -> error, nothing sent
+
+
+@pytest.mark.parametrize("case", [(60, 300, 8, 4, 0.0, 0), (80, 300, 10, 4, 0.4, 0), (120, 400, 12, 4, 0.0, 1), (50, 200, 17, 4, 0.3, 1)])
+def test_leaves_only_oracle_equals_explicit_oracle(case):
+    """CLS_SETS_LEAVES input (include/cls_place.h): the C oracle keeps such node sets lazily (a clade is a member iff
+    a listed leaf lies below it).  Held to the explicit-set oracle -- the restatement of the reference -- on the same
+    indexes: generated both ways, and derived from the explicit one by filtering on kind; records and counters."""
+    nl, rl, k, m, cp, deep = case
+    s = SynthDb(nl, rl, k, m, collapse_prob=cp, deep=deep)
+    t = SynthDb(nl, rl, k, m, collapse_prob=cp, deep=deep, tips_only=True)
+    assert t.flat.leaves_only and not s.flat.leaves_only
+    derived = s.flat.to_leaves_only()
+    assert np.array_equal(t.flat.kmer_hash, s.flat.kmer_hash) and np.array_equal(t.flat.kmer_node_off, derived.kmer_node_off)
+    for j in range(0, s.flat.n_kmers, 97):  # same leaves per k-mer (any order)
+        a, b = int(derived.kmer_node_off[j]), int(derived.kmer_node_off[j + 1])
+        assert sorted(t.flat.node_ids[a:b]) == sorted(derived.node_ids[a:b])
+    back = t.flat.to_explicit()
+    for j in range(0, s.flat.n_kmers, 211):
+        a, b = int(s.flat.kmer_node_off[j]), int(s.flat.kmer_node_off[j + 1])
+        c, d = int(back.kmer_node_off[j]), int(back.kmer_node_off[j + 1])
+        assert sorted(s.flat.node_ids[a:b]) == sorted(back.node_ids[c:d])
+    bases, offsets, _ = s.reads(400, min(rl, 150), frac_random=0.05, err=0.02)
+    for kw in (dict(), dict(remove_intersection=True), dict(min_match_coverage=1.0), dict(max_iterations=3)):
+        want, wst = op.OraclePort(s.flat).place_batch(bases, offsets, op.make_params(**kw), threads=4, want_stats=True)
+        for flat in (t.flat, derived):
+            got, gst = op.OraclePort(flat).place_batch(bases, offsets, op.make_params(**kw), threads=4, want_stats=True)
+            for f in ("status", "one", "rest", "levels", "clade_id"):
+                assert (got[f] == want[f]).all(), (f, kw)
+            for f in ("n_query_kmers", "n_matched", "n_with_root", "leaf_postings"):
+                assert (gst[f] == wst[f]).all(), (f, kw)

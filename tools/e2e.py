@@ -13,6 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 from classeq2_amd import _abi, engine  # noqa: E402
+engine.tuning_from_env()  # CLS_* experiment knobs (the library never reads the environment on its own)
 from classeq2_amd.synth import CONFIGS, SynthDb  # noqa: E402
 
 KINDS = ["ROOT", "NODE", "LEAF"]

@@ -3,6 +3,7 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from classeq2_amd import engine
+engine.tuning_from_env()  # CLS_* experiment knobs (the library never reads the environment on its own)
 from classeq2_amd.synth import SynthDb
 collapse = float(os.environ.get("COLLAPSE", "0"))
 s = SynthDb(10000, 4500, 12, 4, collapse_prob=collapse)

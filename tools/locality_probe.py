@@ -3,6 +3,7 @@ import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from classeq2_amd import engine
+engine.tuning_from_env()  # CLS_* experiment knobs (the library never reads the environment on its own)
 from classeq2_amd.synth import SynthDb
 s = SynthDb(10000, 1500, 12, 4)
 db = engine.PlacementDb(s.flat, device=0)

@@ -3,6 +3,7 @@ import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from classeq2_amd import engine
+engine.tuning_from_env()  # CLS_* experiment knobs (the library never reads the environment on its own)
 from classeq2_amd.synth import SynthDb
 k = int(sys.argv[1]) if len(sys.argv) > 1 else 15
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 2000

@@ -3,6 +3,7 @@ import sys, os, ctypes as C
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from classeq2_amd import engine, synth
+engine.tuning_from_env()  # CLS_* experiment knobs (the library never reads the environment on its own)
 from classeq2_amd.synth import SynthDb
 mode = sys.argv[1]
 s = SynthDb(10000, 1500, 12, 4)
@@ -20,6 +21,9 @@ def xcd(order):
 leaf = truth.astype(np.int64); leaf[truth == 0xFFFFFFFF] = 1 << 40
 if mode == "random": b = bases
 elif mode == "leafpos": b = B[xcd(np.lexsort((pos, leaf)))].reshape(-1).copy()
+elif mode == "posleaf": b = B[xcd(np.lexsort((leaf, pos)))].reshape(-1).copy()          # locus-major: all reads of a locus together, leaves inside
+elif mode.startswith("posbin"):  # locus bins of N bases, leaves inside a bin
+    b = B[xcd(np.lexsort((leaf, pos // int(mode[6:]))))].reshape(-1).copy()
 elif mode == "leafpos_noxcd": b = B[np.lexsort((pos, leaf))].reshape(-1).copy()
 elif mode.startswith("grp"):
     # groups of overlapping reads (same leaf block, same position bin), groups in RANDOM order

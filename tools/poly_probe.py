@@ -3,6 +3,7 @@ import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from classeq2_amd import engine
+engine.tuning_from_env()  # CLS_* experiment knobs (the library never reads the environment on its own)
 from classeq2_amd.synth import SynthDb
 s = SynthDb(10000, 1500, int(sys.argv[1]) if len(sys.argv) > 1 else 12, 4, collapse_prob=0.3)
 db = engine.PlacementDb(s.flat, device=0)

@@ -3,6 +3,7 @@ import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from classeq2_amd import engine
+engine.tuning_from_env()  # CLS_* experiment knobs (the library never reads the environment on its own)
 from classeq2_amd.synth import SynthDb, CONFIGS
 cfg = CONFIGS["C3"]
 s = SynthDb(cfg["n_leaves"], cfg["ref_len"], cfg["k_size"], cfg["m_size"])
