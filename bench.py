@@ -84,7 +84,7 @@ def gather_reference():
     """Measured random-gather rate of this chip (tools/gather_probe.hip, committed summary), if present."""
     try:
         with open(os.path.join(ROOT, "profiles", "gather_probe.json")) as f:
-            return json.load(f)
+            return json.load(f).get("summary")
     except (OSError, ValueError):
         return None
 
@@ -362,9 +362,17 @@ def main():
                 "call_ms": call_ms,
                 # SURVEY.md 8(d)'s model prices streamed posting lists; > 1 by construction for an index that never streams them
                 "survey_model_bytes": model_bytes, "survey_model_frac": model_bytes / ksec / 1e9 / HBM_PEAK_GBS,
-                "gather_reference": gather_reference(),
             },
         }
+        # the kernel reads at random, one 64-byte line per L2 miss: its second roofline is the rate at which the memory
+        # side serves such lines, measured on this chip by tools/gather_probe.hip (profiles/gather_probe.json)
+        gref = gather_reference()
+        if gref:
+            peak_lines = gref["glines_per_s"]["1024_MiB_table_hbm"]
+            lines = (traffic / 64.0 / ksec / 1e9) if traffic else None
+            line["roofline"]["random_line_rate"] = {"achieved_glines_per_s": lines, "peak_glines_per_s": peak_lines,
+                                                    "frac": (lines / peak_lines) if lines else None,
+                                                    "what": gref["what"]}
         if args.dump_records:
             last = (args.steps - 1) & 1
             if world == 1:

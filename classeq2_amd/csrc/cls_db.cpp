@@ -565,3 +565,77 @@ int encode_db(const cls_db_desc* d, EncodedDb& E, std::string& err) {
 }
 
 }  // namespace cls
+
+// ---- host-side self-check of the encoder (tests/test_host_cpu.py; no device involved) ----------------------------
+// For each probe (k-mer hash, clade id): is the clade in the k-mer's node set ACCORDING TO THE ENCODED INDEX?  Answered
+// the way the kernels do: hash table -> set / postings -> tips (every tip of a split tree is collected by walking
+// its records) -> pre-order interval test; the root through its flag.  out[i]: 0 = no, 1 = yes, 2 = k-mer not in the
+// index, 3 = no such clade.
+extern "C" int cls_db_debug_members(const cls_db_desc* d, const uint64_t* hashes, const uint64_t* clade_ids, uint64_t n, uint8_t* out) {
+    try {
+        cls::EncodedDb E;
+        std::string err;
+        const int rc = cls::encode_db(d, E, err);
+        if (rc != CLS_OK) return rc;
+        using namespace cls;
+        std::vector<std::pair<uint64_t, uint32_t>> id2row(E.nodes.size());
+        for (uint32_t r = 0; r < E.nodes.size(); ++r) id2row[r] = {E.nodes[r].id, r};
+        std::sort(id2row.begin(), id2row.end());
+        const uint64_t mask = E.table.size() - 1;
+        std::vector<uint32_t> tips, stk;
+        for (uint64_t i = 0; i < n; ++i) {
+            auto it = std::lower_bound(id2row.begin(), id2row.end(), std::make_pair(clade_ids[i], (uint32_t)0));
+            if (it == id2row.end() || it->first != clade_ids[i]) { out[i] = 3; continue; }
+            const DNode& c = E.nodes[it->second];
+            const uint64_t h = hashes[i];
+            bool found = false, has_root = false, closed = true;
+            tips.clear();
+            if (E.format == FMT_SPLIT) {
+                const TSlot* tab = reinterpret_cast<const TSlot*>(E.table.data());
+                for (uint64_t s = h & mask; tab[s].set != 0; s = (s + 1) & mask) {
+                    if (tab[s].hash != h) continue;
+                    found = true;
+                    const SetRec& sr = E.sets[tab[s].set];
+                    has_root = (sr.vhi_root >> 31) != 0;
+                    if (sr.vlo_lg != 0xFFFFFFFFu) {
+                        const uint32_t lo = sr.vlo_lg & DIRECT_TIP_MASK, hi = sr.vhi_root & 0x7FFFFFFFu;
+                        if (!sr.x) { tips.push_back(lo); if (hi != lo) return CLS_E_INTERNAL; }
+                        else {  // in-order walk of the split tree: {tip_prev, L, tip, R}
+                            const TipRec* recs = reinterpret_cast<const TipRec*>(E.postings.data());
+                            std::vector<std::pair<uint32_t, int>> st{{sr.x, 0}};
+                            tips.push_back(lo);
+                            while (!st.empty()) {
+                                auto [x, phase] = st.back();
+                                st.pop_back();
+                                const TipRec& t = recs[x];
+                                if (phase == 0) { st.push_back({x, 1}); if (t.l) st.push_back({t.l, 0}); }
+                                else { if (tips.back() != t.tip_prev) return CLS_E_INTERNAL; tips.push_back(t.tip); if (t.r) st.push_back({t.r, 0}); }
+                            }
+                            if (tips.back() != hi) return CLS_E_INTERNAL;
+                        }
+                    }
+                    break;
+                }
+            } else {
+                for (uint64_t s = h & mask; E.table[s].loc != SLOT_EMPTY; s = (s + 1) & mask) {
+                    if (E.table[s].hash != h) continue;
+                    found = true;
+                    const uint32_t* w = &E.postings[E.table[s].loc >> LOC_BUCKET_BITS];
+                    has_root = (w[0] & POST_HAS_ROOT) != 0;
+                    closed = (w[0] & POST_CLOSED) != 0;
+                    tips.assign(w + POST_HEADER_WORDS, w + POST_HEADER_WORDS + (w[0] & POST_LEN_MASK));
+                    break;
+                }
+            }
+            if (!found) { out[i] = 2; continue; }
+            bool in = false;
+            if (c.pre == 0) in = has_root;
+            else if (closed) { auto t = std::lower_bound(tips.begin(), tips.end(), c.pre); in = t != tips.end() && *t < c.pre + c.size; }
+            else in = std::binary_search(tips.begin(), tips.end(), c.pre);
+            out[i] = in ? 1 : 0;
+        }
+        return CLS_OK;
+    } catch (...) {
+        return CLS_E_INTERNAL;
+    }
+}

@@ -1412,23 +1412,41 @@ __device__ __forceinline__ void place_read_fast(const DbDev& db, const PlacePara
             pos[s] = p;
         }
     }
-    const uint4* __restrict__ sets = reinterpret_cast<const uint4*>(db.sets);
-    uint4 sr[LS];  // {root split, first tip | lg << 27, last tip | has_root << 31, n_leaf}
-#pragma unroll
-    for (int s = 0; s < LS; ++s) {
-        sr[s] = ldx<uint4, ADDR32>(sets, ((owner >> s) & 1u) ? sid[s] : 0u);  // set 0: {0, MAX, 0, 0}
-        if (STATS && ((owner >> s) & 1u)) ib += 16;
-    }
     wave_sync();
 #pragma unroll
     for (int s = 0; s < LS; ++s) pos[s] = ((owner >> s) & 1u) ? cx.gcnt[pos[s]] : 0u;  // now: the group's weight
-    // ---- A3. |M|, |M_root| ---------------------------------------------------------------------------------
+    wave_sync();  // the three tables are dead from here on: the staging area lies over them
+    // ---- A3. the owners read their set records; |M_root|; the groups that have tips below the root are compacted
+    // into the staging area (64 per chunk; chunk 0 then lives in registers, the others stay in LDS).  A few records
+    // in flight at a time: the wide class would otherwise hold 16 of them per lane in registers.
+    const uint4* __restrict__ sets = reinterpret_cast<const uint4*>(db.sets);
     uint32_t cnt = nm_lane;  // |M| in bits 0..15, |M_root| in bits 16..31 (per lane, then summed)
     uint64_t leafp = 0;
+    uint32_t n_sets = 0;
+    constexpr int G = LS <= 4 ? LS : 4;
 #pragma unroll
-    for (int s = 0; s < LS; ++s) {
-        cnt += ((sr[s].z >> 31) * pos[s]) << 16;
-        if (STATS) leafp += (uint64_t)pos[s] * sr[s].w;
+    for (int g0 = 0; g0 < LS; g0 += G) {
+        uint4 sr[G];  // {root split, first tip | lg << 27, last tip | has_root << 31, n_leaf}
+#pragma unroll
+        for (int i = 0; i < G; ++i) {
+            const int s = g0 + i;
+            const bool own = s < LS && ((owner >> s) & 1u);
+            sr[i] = ldx<uint4, ADDR32>(sets, own ? sid[s < LS ? s : 0] : 0u);  // set 0: {0, MAX, 0, 0}
+            if (STATS && own) ib += 16;
+        }
+#pragma unroll
+        for (int i = 0; i < G; ++i) {
+            const int s = g0 + i;
+            if (s >= LS) continue;
+            const uint32_t w = pos[s];  // 0 unless this lane owns the group
+            cnt += ((sr[i].z >> 31) * w) << 16;
+            if (STATS) leafp += (uint64_t)w * sr[i].w;
+            const bool live = ((owner >> s) & 1u) && sr[i].y != 0xFFFFFFFFu;
+            const uint64_t m = __ballot(live);
+            if (live)
+                cx.stage[n_sets + popc64(m & ((1ull << lane) - 1))] = uint4{sr[i].y & DIRECT_TIP_MASK, sr[i].z & 0x7FFFFFFFu, sr[i].x, w};
+            n_sets += popc64(m);
+        }
     }
     cnt = wave_sum(cnt);
     const uint32_t n_m = cnt & 0xFFFFu, n_root = cnt >> 16;
@@ -1436,7 +1454,7 @@ __device__ __forceinline__ void place_read_fast(const DbDev& db, const PlacePara
         for (int o = 32; o > 0; o >>= 1) leafp += ((uint64_t)__shfl_xor((uint32_t)(leafp >> 32), o) << 32) | __shfl_xor((uint32_t)leafp, o);
         put_stats(nk, n_m, n_root, leafp);
     }
-    if (profile_stop == 2) { write_record(out, r, 0xFE, (int32_t)(sr[0].z + sr[LS - 1].w), 0, 0, 0); return; }
+    if (profile_stop == 2) { write_record(out, r, 0xFE, (int32_t)n_sets, 0, 0, 0); return; }
     // ---- B. thresholds ------------------------------------------------------------------------------
     if (n_m == 0) { put_index_bytes(); write_record(out, r, CLS_UNCLASSIFIABLE_NO_MATCH, 0, 0, 0, 0); return; }
     if (n_root == 0) { put_index_bytes(); write_record(out, r, CLS_UNCLASSIFIABLE_NO_ROOT, 0, 0, 0, 0); return; }
@@ -1448,18 +1466,6 @@ __device__ __forceinline__ void place_read_fast(const DbDev& db, const PlacePara
         const double expected = round((double)n_m * prm.min_match_coverage);
         const uint64_t exp_usize = (expected != expected) ? 0ull : (uint64_t)expected;
         if ((uint64_t)n_root < exp_usize) { put_index_bytes(); write_record(out, r, CLS_UNCLASSIFIABLE_COVERAGE, (int32_t)n_root, 0, 0, 0); return; }
-    }
-    // the groups that have tips below the root are compacted into the staging area (64 per chunk; chunk 0 then
-    // lives in registers, the others stay in LDS); the tables are dead from here on: the staging area lies over them
-    uint32_t n_sets = 0;
-    wave_sync();
-#pragma unroll
-    for (int s = 0; s < LS; ++s) {
-        const bool live = ((owner >> s) & 1u) && sr[s].y != 0xFFFFFFFFu;
-        const uint64_t m = __ballot(live);
-        if (live)
-            cx.stage[n_sets + popc64(m & ((1ull << lane) - 1))] = uint4{sr[s].y & DIRECT_TIP_MASK, sr[s].z & 0x7FFFFFFFu, sr[s].x, pos[s]};
-        n_sets += popc64(m);
     }
     descend_groups<(SLOTS * 64 < 1024), ADDR32, POLY, STATS>(db, prm, cx, n_sets, P, r, out, ib);
     put_index_bytes();

@@ -137,3 +137,47 @@ def test_leaves_only_descriptor_validation():
     assert engine.lib().cls_db_validate(C.byref(d)) != 0
     d.abi_version = 3
     assert engine.lib().cls_db_validate(C.byref(d)) != 0
+
+
+@pytest.mark.parametrize("case", [(40, 1500, 21, 0, 0.0, 0, 1), (60, 300, 9, 4, 0.3, 0, 0), (80, 300, 12, 4, 0.0, 1, 1), (50, 200, 8, 4, 0.4, 0, 2),
+                                  (64, 400, 11, 4, 0.0, 2, 0), (30, 200, 7, 3, 0.5, 0, 1)])
+def test_encoded_index_answers_membership_like_the_node_sets(case):
+    """The encoder (tip sets shared between k-mers, split trees, hash table, sorted-list postings) checked on the host,
+    no device: for every k-mer of the index and a sample of clades, `clade in nodes(k-mer)` answered from the ENCODED
+    index (cls_db_debug_members walks the same tables the kernels read) equals the answer of the node sets themselves."""
+    from tests.helpers import drop_random_nodes, truncate_random_sets
+    nl, rl, k, m, cp, deep, mode = case
+    s = SynthDb(nl, rl, k, m, collapse_prob=cp, deep=deep, seed_tree=203, seed_refseq=204)
+    flats = [s.flat, s.flat.to_leaves_only()]
+    if mode == 1:
+        flats = [truncate_random_sets(s.flat, 0.1, seed=202)]
+    elif mode == 2:
+        flats = [drop_random_nodes(s.flat, 0.15, seed=5)]
+    L = engine.lib()
+    L.cls_db_debug_members.argtypes = [C.POINTER(_abi.DbDesc), C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
+    L.cls_db_debug_members.restype = C.c_int
+    rng = np.random.default_rng(1)
+    truth_flat = flats[0]
+    ids = truth_flat.nodes["id"]
+    off = truth_flat.kmer_node_off.astype(np.int64)
+    sample = np.arange(0, truth_flat.n_kmers, max(1, truth_flat.n_kmers // 4000))  # (a few thousand k-mers keep the test in seconds)
+    nk = len(sample)
+    per = 12
+    hashes = np.repeat(truth_flat.kmer_hash[sample], per)
+    clades = np.empty(nk * per, dtype=np.uint64)
+    want = np.empty(nk * per, dtype=np.uint8)
+    for j, kj in enumerate(sample):
+        members = truth_flat.node_ids[off[kj]:off[kj + 1]]
+        pick = np.concatenate([[ids[0]], rng.choice(ids, per - 1 - min(4, len(members))), rng.choice(members, min(4, len(members))) if len(members) else []])
+        clades[j * per:(j + 1) * per] = pick
+        want[j * per:(j + 1) * per] = np.isin(pick, members)
+    for flat in flats:
+        out = np.full(nk * per, 9, dtype=np.uint8)
+        d = flat.desc()
+        assert L.cls_db_debug_members(C.byref(d), hashes.ctypes.data, clades.ctypes.data, nk * per, out.ctypes.data) == 0
+        bad = np.nonzero(out != want)[0]
+        assert len(bad) == 0, (len(bad), int(bad[0]), int(out[bad[0]]), int(want[bad[0]]))
+    absent = np.array([1, 2, 3], dtype=np.uint64)
+    out = np.zeros(3, dtype=np.uint8)
+    d = flats[0].desc()
+    assert L.cls_db_debug_members(C.byref(d), absent.ctypes.data, ids[:3].copy().ctypes.data, 3, out.ctypes.data) == 0 and (out == 2).all()
