@@ -357,8 +357,9 @@ def main():
                 "traffic_frac": (traffic / ksec / 1e9 / HBM_PEAK_GBS) if traffic else None,
                 "overfetch": (traffic / need) if traffic and need else None,
                 "kernel": kname, "kernel_ms": kernel_ms, "kernel_launches_timed": int(k_cnt),
-                "kernels_timed": "kernel_ms = the wave-per-read placement kernel of the <= 320-k-mer class only (HIP events on "
-                                 "the launch stream); call_ms = the whole call: locality keys + sort + classify + every class",
+                "kernels_timed": "kernel_ms = the placement kernel named in `kernel` only (HIP events on the launch stream: the "
+                                 "wave-per-read kernel of the <= 320-k-mer class, or the LDS-tiled kernel when the handle is provisioned "
+                                 "for long reads); call_ms = the whole call: locality keys + sort + classify + every class",
                 "call_ms": call_ms,
                 # SURVEY.md 8(d)'s model prices streamed posting lists; > 1 by construction for an index that never streams them
                 "survey_model_bytes": model_bytes, "survey_model_frac": model_bytes / ksec / 1e9 / HBM_PEAK_GBS,

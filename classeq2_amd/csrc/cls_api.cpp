@@ -451,7 +451,11 @@ extern "C" int cls_place_batch_device(cls_db* db, const void* d_bases, const voi
 extern "C" int cls_db_kernel_name(const cls_db* db, char* buf, size_t len) {
     if (!db || !buf || !len) return fail(CLS_E_INVALID_ARG, "cls_db_kernel_name: null argument");
     try {
-        const std::string s = cls::dominant_kernel_name(db->dev, false);
+        uint64_t max_len;
+        { std::lock_guard<std::mutex> g(const_cast<cls_db*>(db)->ws_mu); max_len = db->max_read_len; }
+        // (as cls_place_batch_device would plan a launch: long reads only when the caller opted in)
+        const cls::PlacePlan plan = cls::plan_place(db->dev, 4096, (uint32_t)db->n_cu, false, (uint32_t)(2 * max_len), max_len ? 4096 : 0);
+        const std::string s = cls::dominant_kernel_name(db->dev, false, &plan);
         snprintf(buf, len, "%s", s.c_str());
         return CLS_OK;
     } catch (...) {

@@ -36,9 +36,9 @@ struct PlacePlan {
 // such reads the batch may hold (bounds the number of workspace slices).
 PlacePlan plan_place(const DbDev& db, uint32_t n_reads, uint32_t n_cu, bool stats, uint32_t long_cap, uint32_t n_long);
 // Template instance of the class-0 placement kernel launch_place() picks for `db` (as rocprofv3 names it).
-std::string dominant_kernel_name(const DbDev& db, bool stats);
+std::string dominant_kernel_name(const DbDev& db, bool stats, const PlacePlan* plan = nullptr);
 // Asynchronous on `stream`; all pointers are device pointers; `d_ws` holds plan.ws_bytes.
-// `ev_start`/`ev_stop` (may be null) are recorded around the class-0 placement kernel.
+// `ev_start`/`ev_stop` (may be null) are recorded around the dominant placement kernel (dominant_kernel_name).
 hipError_t launch_place(const DbDev& db, const PlaceParams& prm, const PlacePlan& plan, const uint8_t* d_bases,
                         const uint64_t* d_offsets, uint32_t n_reads, cls_placement* d_out, cls_query_stats* d_stats,
                         uint32_t* d_ws, hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop);

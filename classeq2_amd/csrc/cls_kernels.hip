@@ -1248,6 +1248,12 @@ __device__ __forceinline__ void descend_groups(const DbDev& db, const PlaceParam
             continue;
         }
         const uint32_t a0 = P.s[0] + 1, a1 = P.s[6];  // first child = [a0, a1), second = [a1, end of the parent)
+        // The level's two memory round trips are taken off its dependent chain (waves spent two thirds of their time
+        // parked on them): a group of chunk 0 that has tips on both sides of a1 will need one half of its split record
+        // whichever child wins, so the whole 16-byte record is requested NOW, before the counting and the reduction ...
+        const bool str_any0 = vlo < a1 && vhi >= a1;
+        const uint4 rec0 = ldx<uint4, ADDR32>(reinterpret_cast<const uint4*>(half), str_any0 ? x : 0u);  // {tip_prev, L, tip, R}
+        if (STATS && str_any0) ib += 16;
         uint32_t c3 = 0, c3b = 0;  // per lane: k-mers in a | in b << 10 | in both << 20
         auto count = [&](uint32_t lo_, uint32_t hi_, uint32_t w) {
             const uint32_t ina = lo_ < a1 ? w : 0u;    // lo >= a0 for an active set, MAX for an inactive one
@@ -1280,13 +1286,22 @@ __device__ __forceinline__ void descend_groups(const DbDev& db, const PlaceParam
             return;
         }
         const bool right = only_b > only_a;
-        P = load_node(db.nodes, fc + (right ? 1u : 0u));  // (a speculative load of both children was sunk below the tie test by the compiler anyway)
+        // ... and the chosen child's node record is requested before the narrowing, not waited for until after it
+        // (the narrowing of a read's last level is wasted work: one level in sixteen)
+        P = load_node(db.nodes, fc + (right ? 1u : 0u));
+        __builtin_amdgcn_sched_barrier(0);  // keep the request up here (the scheduler sinks scalar loads to their first use)
         if (STATS && lane == 0) ib += 32;
-        if (P.s[3] == 0) {  // no non-LEAF child below the chosen clade (update_introspection_node.rs:45-85)
-            const uint32_t cn = right ? cnt_b : cnt_a, on = right ? only_b : only_a;
-            write_record(out, r, CLS_IDENTITY_FOUND, (int32_t)(rm ? on : cn), (int32_t)(rm ? U - cn : U - on), (uint32_t)iteration,
-                         ((uint64_t)P.s[5] << 32) | P.s[4]);
-            return;
+        {   // chunk 0 from the record requested above
+            const bool str = str_any0 && (right || vlo != a0);
+            if (!right) {
+                const bool gone = vlo >= a1 || vlo == a0;  // no tip strictly below the first child
+                if (str) { vhi = rec0.x; x = rec0.y; }
+                if (gone) { vlo = 0xFFFFFFFFu; vhi = 0; }
+            } else {
+                if (str) { vlo = rec0.z; x = rec0.w; }
+                const bool gone = vhi < a1 || vlo == a1;  // nothing in the second child, or it is the tip itself
+                if (gone) { vlo = 0xFFFFFFFFu; vhi = 0; }
+            }
         }
         // narrow: a set with tips on both sides of a1 reads 8 bytes of its split node (the half for the side
         // taken); everything else is arithmetic on (lo, hi).  Inactive afterwards = {MAX, 0}.
@@ -1304,12 +1319,17 @@ __device__ __forceinline__ void descend_groups(const DbDev& db, const PlaceParam
                 if (gone) { lo_ = 0xFFFFFFFFu; hi_ = 0; }
             }
         };
-        narrow(vlo, vhi, x);
 #pragma unroll 1
         for (uint32_t c = 1; c < n_chunks; ++c) {
             uint4 g = cx.stage[c * 64 + lane];
             narrow(g.x, g.y, g.z);
             cx.stage[c * 64 + lane] = g;
+        }
+        if (P.s[3] == 0) {  // no non-LEAF child below the chosen clade (update_introspection_node.rs:45-85)
+            const uint32_t cn = right ? cnt_b : cnt_a, on = right ? only_b : only_a;
+            write_record(out, r, CLS_IDENTITY_FOUND, (int32_t)(rm ? on : cn), (int32_t)(rm ? U - cn : U - on), (uint32_t)iteration,
+                         ((uint64_t)P.s[5] << 32) | P.s[4]);
+            return;
         }
     }
 }
@@ -2502,9 +2522,11 @@ size_t blk_smem(const DbDev& db) {
 }
 }  // namespace
 
-std::string dominant_kernel_name(const DbDev& db, bool stats) {
+std::string dominant_kernel_name(const DbDev& db, bool stats, const PlacePlan* plan) {
     const std::string sl = std::to_string(CLS_SLOTS[0]) + ", " + std::to_string(CLS_SET_BITS[0]) + ", " + (stats ? "true" : "false");
     auto b = [](bool v) { return std::string(v ? "true" : "false"); };
+    if (plan && plan->grid_tile)  // a launch provisioned for long reads: the LDS-tiled kernel is the one that is timed
+        return "place_tile_kernel<" + std::to_string(plan->tile_threads) + ", " + b(db.canonical != 0) + ", " + b(stats) + ", " + b(db.addr32 != 0) + ">";
     if (use_fast(db))
         return "place_fast_kernel<" + sl + ", " + b(fast_mode(db) == 2 || db.addr32) + ", " + std::to_string(fast_mode(db)) + ", " + b(!db.binary_tree) + ">";
     if (db.format == FMT_SPLIT) return "place_split_kernel<" + sl + ", " + b(!db.binary_tree) + ">";
@@ -2706,9 +2728,12 @@ hipError_t launch_place(const DbDev& db, const PlaceParams& prm, const PlacePlan
         else { if (binary) CLS_LAUNCH(false, true); else CLS_LAUNCH(false, false); }
 #undef CLS_LAUNCH
     };
-    if (ev_start) (void)hipEventRecord(ev_start, stream);
+    // the timed kernel (cls_db_kernel_time): the LDS-tiled long-read kernel in a launch provisioned for long reads,
+    // else the wave-per-read kernel of the <= 320-k-mer class
+    const bool time_tile = plan.grid_tile != 0;
+    if (ev_start && !time_tile) (void)hipEventRecord(ev_start, stream);
     launch_class(std::integral_constant<int, CLS_SLOTS[0]>{}, std::integral_constant<int, CLS_SET_BITS[0]>{}, 0);
-    if (ev_stop) (void)hipEventRecord(ev_stop, stream);
+    if (ev_stop && !time_tile) (void)hipEventRecord(ev_stop, stream);
     if (hipGetLastError() != hipSuccess) return hipErrorLaunchFailure;
     launch_class(std::integral_constant<int, CLS_SLOTS[1]>{}, std::integral_constant<int, CLS_SET_BITS[1]>{}, 1);
     if (hipGetLastError() != hipSuccess) return hipErrorLaunchFailure;
@@ -2731,6 +2756,7 @@ hipError_t launch_place(const DbDev& db, const PlaceParams& prm, const PlacePlan
     }
     if (plan.grid_tile) {  // class 3: long reads, every state in LDS; reads it cannot hold are appended to class 4's list
         if (hipGetLastError() != hipSuccess) return hipErrorLaunchFailure;
+        if (ev_start) (void)hipEventRecord(ev_start, stream);
 #define CLS_LAUNCH_TILE(TH, CN, ST, A32)                                                                                          \
     do {                                                                                                                          \
         auto kfn = place_tile_kernel<TH, CN, ST, A32>;                                                                            \
@@ -2746,6 +2772,7 @@ hipError_t launch_place(const DbDev& db, const PlaceParams& prm, const PlacePlan
 #undef CLS_LAUNCH_TILE2
 #undef CLS_LAUNCH_TILE3
 #undef CLS_LAUNCH_TILE
+        if (ev_stop) (void)hipEventRecord(ev_stop, stream);
     }
     if (plan.grid_long) {  // class 4: reads beyond what the LDS holds (and every long read of the other index shapes): state in the workspace
         if (hipGetLastError() != hipSuccess) return hipErrorLaunchFailure;

@@ -230,8 +230,9 @@ int cls_place_batch_device(cls_db* db, const void* d_bases, const void* d_offset
  * their per-k-mer state in the workspace: 80 bytes per base and resident workgroup.  At most 2^25. */
 int cls_db_set_max_read_len(cls_db* db, uint64_t n_bases);
 
-/* Device time of the DOMINANT placement kernel (the per-read placement kernel of the
- * 320-k-mer class), accumulated over every cls_place_batch_device() launch on this
+/* Device time of the DOMINANT placement kernel (the wave-per-read kernel of the
+ * 320-k-mer class; for a handle provisioned for long reads, cls_db_set_max_read_len,
+ * the LDS-tiled long-read kernel), accumulated over every cls_place_batch_device() launch on this
  * handle since the last reset: HIP events recorded around that kernel on the
  * caller's stream.  Waits for the launches still in flight.  Measurement aid for
  * bench.py's roofline figure; `reset` != 0 clears the accumulators afterwards. */
