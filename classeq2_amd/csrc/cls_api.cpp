@@ -196,7 +196,7 @@ extern "C" int cls_db_create(const cls_db_desc* d, int device, cls_db** out) {
         db->device = device;
         db->n_cu = prop.multiProcessorCount;
         auto up = [&](void** dst, const void* src, size_t bytes) -> hipError_t {
-            hipError_t e = hipMalloc(dst, bytes ? bytes : 16);
+            hipError_t e = hipMalloc(dst, bytes + 64);  // (tail pad: the kernels read node records in pairs and 16-byte entries speculatively)
             if (e != hipSuccess) return e;
             return bytes ? hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice) : hipSuccess;
         };

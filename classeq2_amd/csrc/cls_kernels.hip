@@ -39,6 +39,12 @@ constexpr int WAVES_PER_BLOCK = 4;
 #ifndef FAST_MIN_WAVES
 #define FAST_MIN_WAVES 5  // 96 VGPRs: 5 workgroups per CU measured best on C3 (4: 9.2 ms, 5: 8.5, 6: 9.1 with more spills)
 #endif
+#ifndef CLS_DESCENT_SPEC
+#define CLS_DESCENT_SPEC 0  // 1: a level's split record (chunk 0) and node record are requested off its dependent chain (measured: 7.21 ms against 7.19 ms on C3 at the same occupancy, and twice the split bytes requested: off)
+#endif
+#ifndef CLS_NARROW_CANON_BITS
+#define CLS_NARROW_CANON_BITS 9  // LDS tables of the narrow class on a strand-symmetric index (at most 160 lookups per read): 2^bits entries
+#endif
 #ifndef FAST_MIN_WAVES_WIDE
 #define FAST_MIN_WAVES_WIDE 4  // the 16-slot class keeps more state per lane: forcing 96 VGPRs on it spills 74 of them
 #endif
@@ -1251,9 +1257,11 @@ __device__ __forceinline__ void descend_groups(const DbDev& db, const PlaceParam
         // The level's two memory round trips are taken off its dependent chain (waves spent two thirds of their time
         // parked on them): a group of chunk 0 that has tips on both sides of a1 will need one half of its split record
         // whichever child wins, so the whole 16-byte record is requested NOW, before the counting and the reduction ...
+#if CLS_DESCENT_SPEC
         const bool str_any0 = vlo < a1 && vhi >= a1;
         const uint4 rec0 = ldx<uint4, ADDR32>(reinterpret_cast<const uint4*>(half), str_any0 ? x : 0u);  // {tip_prev, L, tip, R}
         if (STATS && str_any0) ib += 16;
+#endif
         uint32_t c3 = 0, c3b = 0;  // per lane: k-mers in a | in b << 10 | in both << 20
         auto count = [&](uint32_t lo_, uint32_t hi_, uint32_t w) {
             const uint32_t ina = lo_ < a1 ? w : 0u;    // lo >= a0 for an active set, MAX for an inactive one
@@ -1291,6 +1299,14 @@ __device__ __forceinline__ void descend_groups(const DbDev& db, const PlaceParam
         P = load_node(db.nodes, fc + (right ? 1u : 0u));
         __builtin_amdgcn_sched_barrier(0);  // keep the request up here (the scheduler sinks scalar loads to their first use)
         if (STATS && lane == 0) ib += 32;
+#if !CLS_DESCENT_SPEC
+        if (P.s[3] == 0) {  // no non-LEAF child below the chosen clade (update_introspection_node.rs:45-85)
+            const uint32_t cn = right ? cnt_b : cnt_a, on = right ? only_b : only_a;
+            write_record(out, r, CLS_IDENTITY_FOUND, (int32_t)(rm ? on : cn), (int32_t)(rm ? U - cn : U - on), (uint32_t)iteration,
+                         ((uint64_t)P.s[5] << 32) | P.s[4]);
+            return;
+        }
+#else
         {   // chunk 0 from the record requested above
             const bool str = str_any0 && (right || vlo != a0);
             if (!right) {
@@ -1303,6 +1319,7 @@ __device__ __forceinline__ void descend_groups(const DbDev& db, const PlaceParam
                 if (gone) { vlo = 0xFFFFFFFFu; vhi = 0; }
             }
         }
+#endif
         // narrow: a set with tips on both sides of a1 reads 8 bytes of its split node (the half for the side
         // taken); everything else is arithmetic on (lo, hi).  Inactive afterwards = {MAX, 0}.
         auto narrow = [&](uint32_t& lo_, uint32_t& hi_, uint32_t& x_) {
@@ -1319,18 +1336,23 @@ __device__ __forceinline__ void descend_groups(const DbDev& db, const PlaceParam
                 if (gone) { lo_ = 0xFFFFFFFFu; hi_ = 0; }
             }
         };
+#if !CLS_DESCENT_SPEC
+        narrow(vlo, vhi, x);
+#endif
 #pragma unroll 1
         for (uint32_t c = 1; c < n_chunks; ++c) {
             uint4 g = cx.stage[c * 64 + lane];
             narrow(g.x, g.y, g.z);
             cx.stage[c * 64 + lane] = g;
         }
+#if CLS_DESCENT_SPEC
         if (P.s[3] == 0) {  // no non-LEAF child below the chosen clade (update_introspection_node.rs:45-85)
             const uint32_t cn = right ? cnt_b : cnt_a, on = right ? only_b : only_a;
             write_record(out, r, CLS_IDENTITY_FOUND, (int32_t)(rm ? on : cn), (int32_t)(rm ? U - cn : U - on), (uint32_t)iteration,
                          ((uint64_t)P.s[5] << 32) | P.s[4]);
             return;
         }
+#endif
     }
 }
 
@@ -1500,7 +1522,10 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, SLOTS <= 5 ? FAST_MIN_WAVES :
     const uint32_t wave = threadIdx.x >> 6;
     // (MODE 2 keeps forward ++ reverse-complement ASCII in `ascii_cap` bytes and packs nothing)
     const uint32_t packed_words = MODE == 2 ? 0u : ((ascii_cap >> 4) + 2 + 3) & ~3u;  // whole 16-byte units: what follows stays 16-byte aligned
-    static_assert((12u << SET_BITS) >= 16u * 64 * SLOTS, "the staging area must fit over the three tables");
+    // the staging area must fit over the three tables (combinations that do not are instantiated by the dispatch
+    // macros but never launched: set_bits_of)
+    constexpr bool FITS = (12u << SET_BITS) >= 16u * 64 * (MODE == 1 ? (SLOTS + 1) / 2 : SLOTS);
+    if constexpr (FITS) {
     const uint32_t per_wave = ascii_cap + 4u * packed_words + (12u << SET_BITS) + (POLY ? 12u * FAST_MAX_ARITY + 16u : 0u);
     FastCtx cx;
     cx.ascii = smem + wave * per_wave;
@@ -1536,6 +1561,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, SLOTS <= 5 ? FAST_MIN_WAVES :
         }
         place_read_fast<SLOTS, SET_BITS, STATS, ADDR32, MODE, POLY>(db, prm, cx, bases, b0, b1, r, out, stats, profile_stop);
         wave_sync();
+    }
     }
 }
 
@@ -2166,6 +2192,17 @@ __host__ __device__ inline size_t tile_smem(uint32_t max_lookups, uint32_t max_b
     return 4ull * tile_packed_words(max_bases) + 4ull * TILE_SET_ENTRIES + 8ull * max_lookups + 4ull * max_lookups + 16;
 }
 
+// both children of a binary clade (consecutive rows): one 64-byte scalar load
+struct snode_pair_t { uint32_t s[16]; };
+__device__ __forceinline__ snode_pair_t load_node_pair(const DNode* nodes, uint32_t row) {
+    typedef __attribute__((address_space(4))) const uint32_t as4_u32;
+    as4_u32* p = (as4_u32*)(uintptr_t)(nodes + __builtin_amdgcn_readfirstlane(row));
+    snode_pair_t r;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) r.s[i] = p[i];
+    return r;
+}
+
 template <int THREADS, bool CANON, bool STATS, bool ADDR32>
 __global__ __launch_bounds__(THREADS) void place_tile_kernel(DbDev db, PlaceParams prm, const uint8_t* __restrict__ bases,
                                                              const uint64_t* __restrict__ offsets, const uint32_t* __restrict__ list,
@@ -2178,6 +2215,7 @@ __global__ __launch_bounds__(THREADS) void place_tile_kernel(DbDev db, PlacePara
     uint32_t* const cset = packed + tile_packed_words(max_bases);
     uint64_t* const hot = reinterpret_cast<uint64_t*>(cset + TILE_SET_ENTRIES);   // {first tip : 24, last tip : 24, weight : 16}
     uint32_t* const xs = reinterpret_cast<uint32_t*>(hot + max_lookups);           // root split of the entry's set
+    uint32_t* const wsid = xs;  // front only: per window its tip-set id | palindrome << 31 if it is the first with its code, else 0
     const uint32_t tid = threadIdx.x, lane = tid & 63;
     const uint32_t k = db.k;
     const uint32_t kmask = (1u << (2 * k)) - 1u;  // k <= 15
@@ -2229,55 +2267,83 @@ __global__ __launch_bounds__(THREADS) void place_tile_kernel(DbDev db, PlacePara
         if (tid == 0) { sh.n_groups = 0; sh.n_m = 0; sh.n_root = 0; sh.overflow = 0; sh.ib = 0; sh.leafp = 0; }
         if (tid < 6) (&sh.cnt[0][0])[tid] = 0;
         if (__syncthreads_or(bad ? 1 : 0)) { put_stats(0, 0, 0, 0, 0); record(CLS_ERR_INVALID_BASE, 0, 0, 0, 0); continue; }
-        // ---- A2. lookups, distinct k-mers, state entries ----------------------------------------------------------
+        // code (and palindrome flag) of lookup j: forward windows first, then those of the reverse complement (kmers_map.rs:387-395)
+        auto code_of = [&](uint32_t j, bool& palindrome) -> uint32_t {
+            const bool rc = j >= nf;
+            const uint32_t p = rc ? (nf - 1) - (j - nf) : j;  // window start; the rc list runs backwards over the windows
+            const uint32_t w = p >> 4, s2 = (2 * p) & 31;
+            const uint32_t d0 = packed[w], d1 = packed[w + 1];
+            uint32_t code = (uint32_t)((((uint64_t)d1 << 32) | d0) >> s2) & kmask;
+            uint32_t rcc = __builtin_bitreverse32(code ^ (0xAAAAAAAAu & kmask));
+            rcc = ((rcc >> 1) & 0x55555555u) | ((rcc & 0x55555555u) << 1);
+            rcc >>= (32 - 2 * k);
+            palindrome = code == rcc;
+            return CANON ? (rcc < code ? rcc : code) : (rc ? rcc : code);
+        };
+        // ---- A2a. lookups + distinct k-mers, in passes over hash partitions of the codes: wsid[j] = tip-set id of
+        // window j if it is the FIRST with its code (HashSet<u64> of hashes) and the k-mer is in the index, else 0 ------
         const uint32_t n_pass = (n_look + pass_codes - 1) / pass_codes;
-        uint32_t nm_t = 0, nroot_t = 0, ib_t = 0;
-        uint64_t leafp_t = 0;
+        uint32_t ib_t = 0;
         for (uint32_t pass = 0; pass < n_pass; ++pass) {
             if (pass) __syncthreads();  // the previous pass' set is no longer probed
             for (uint32_t i = tid; i < TILE_SET_ENTRIES; i += THREADS) cset[i] = SET_EMPTY;
             __syncthreads();
-            for (uint32_t base = 0; base < n_look; base += THREADS) {
-                const uint32_t j = base + tid;
-                bool mine = false;
-                uint32_t code = 0, kw = 0;
-                if (j < n_look) {
-                    const bool rc = j >= nf;
-                    const uint32_t p = rc ? (nf - 1) - (j - nf) : j;  // window start; the rc list runs backwards over the windows
-                    const uint32_t w = p >> 4, s2 = (2 * p) & 31;
-                    const uint32_t d0 = packed[w], d1 = packed[w + 1];
-                    code = (uint32_t)((((uint64_t)d1 << 32) | d0) >> s2) & kmask;
-                    uint32_t rcc = __builtin_bitreverse32(code ^ (0xAAAAAAAAu & kmask));
-                    rcc = ((rcc >> 1) & 0x55555555u) | ((rcc & 0x55555555u) << 1);
-                    rcc >>= (32 - 2 * k);
-                    const bool palindrome = code == rcc;
-                    code = CANON ? (rcc < code ? rcc : code) : (rc ? rcc : code);
-                    kw = (CANON && !palindrome) ? 2u : 1u;
-                    mine = n_pass == 1 || (uint32_t)(((uint64_t)mix32(code) * n_pass) >> 32) == pass;
-                }
-                uint32_t sid = 0;
-                if (mine) { sid = ldx<uint32_t, ADDR32>(direct, code) & SET_ID_MASK; if (STATS) ib_t += 4; }
-                bool first = false;
-                if (sid) {  // HashSet<u64> of hashes: the first k-mer with this code keeps the entry
+            for (uint32_t j = tid; j < n_look; j += THREADS) {
+                bool palindrome;
+                const uint32_t code = code_of(j, palindrome);
+                if (n_pass != 1 && (uint32_t)(((uint64_t)mix32(code) * n_pass) >> 32) != pass) continue;
+                uint32_t sid = ldx<uint32_t, ADDR32>(direct, code) & SET_ID_MASK;
+                if (STATS) ib_t += 4;
+                if (sid) {
                     uint32_t pos = (code * 2654435761u) & (TILE_SET_ENTRIES - 1);
                     for (uint32_t probes = 0;; ++probes) {
-                        if (probes == TILE_SET_ENTRIES) { sh.overflow = 1; break; }  // (a partition that does not fit: spill the read)
+                        if (probes == TILE_SET_ENTRIES) { sh.overflow = 1; sid = 0; break; }  // (a partition that does not fit: spill the read)
                         const uint32_t old = atomicCAS(&cset[pos], SET_EMPTY, code);
-                        if (old == SET_EMPTY) { first = true; break; }
-                        if (old == code) break;
+                        if (old == SET_EMPTY) break;
+                        if (old == code) { sid = 0; break; }
                         pos = (pos + 1) & (TILE_SET_ENTRIES - 1);
                     }
                 }
-                uint4 sr = uint4{0u, 0xFFFFFFFFu, 0u, 0u};
-                if (first) { sr = ldx<uint4, ADDR32>(sets, sid); if (STATS) ib_t += 16; }
-                const bool has_root = (sr.z >> 31) != 0, has_tips = sr.y != 0xFFFFFFFFu;
-                if (first) { nm_t += kw; nroot_t += has_root ? kw : 0u; if (STATS) leafp_t += (uint64_t)kw * sr.w; }
-                const bool live = first && has_root && has_tips;
-                const uint32_t g = append_slot(live, &sh.n_groups);
-                if (live) {
-                    hot[g] = (uint64_t)(sr.y & TILE_TIP_MASK) | ((uint64_t)(sr.z & TILE_TIP_MASK) << TILE_TIP_BITS) | ((uint64_t)kw << (2 * TILE_TIP_BITS));
-                    xs[g] = sr.x;
-                }
+                wsid[j] = sid ? (sid | ((CANON && !palindrome) ? 0u : 0x80000000u)) : 0u;  // bit 31: the lookup stands for ONE k-mer
+            }
+        }
+        __syncthreads();
+        if (sh.overflow) {  // hand the read to the workspace kernel
+            if (tid == 0) spill_list[atomicAdd(spill_len, 1u)] = r;
+            continue;
+        }
+        // ---- A2b. state entries.  Consecutive windows mostly share their tip set (a set's k-mers are the windows between
+        // two mutation boundaries of a lineage): runs of equal set ids among a wavefront's 64 consecutive windows
+        // become ONE entry weighted by the run, and only the run's head reads the 16-byte set record. --------------
+        uint32_t nm_t = 0, nroot_t = 0;
+        uint64_t leafp_t = 0;
+        for (uint32_t base = 0; base < n_look; base += THREADS) {
+            const uint32_t j = base + tid;
+            const uint32_t v = j < n_look ? wsid[j] : 0u;
+            __syncthreads();  // every window of this block is read before entries (xs[g], g <= j) overwrite the same words
+            const uint32_t sid = v & SET_ID_MASK;
+            const uint32_t kw = !sid ? 0u : (v >> 31) ? 1u : 2u;
+            const uint32_t prev_sid = __shfl_up(sid, 1);
+            const bool member = sid != 0;
+            const bool head = member && (lane == 0 || prev_sid != sid);
+            // weight of the run that starts at a head: inclusive prefix sums of kw, run end = lane before the next head / non-member
+            uint32_t ps = kw;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(ps, o); if ((int)lane >= o) ps += t; }
+            const uint64_t stop = __ballot(head || !member);   // lanes at which a run cannot continue
+            const uint64_t later = lane == 63 ? 0ull : (stop >> (lane + 1));
+            const uint32_t end = later ? lane + (uint32_t)__ffsll((unsigned long long)later) - 1u : 63u;  // last lane of my run (if I am a head)
+            const uint32_t ps_end = __shfl(ps, (int)end);
+            const uint32_t w = head ? ps_end - (ps - kw) : 0u;
+            uint4 sr = uint4{0u, 0xFFFFFFFFu, 0u, 0u};
+            if (head) { sr = ldx<uint4, ADDR32>(sets, sid); if (STATS) ib_t += 16; }
+            const bool has_root = (sr.z >> 31) != 0, has_tips = sr.y != 0xFFFFFFFFu;
+            if (head) { nm_t += w; nroot_t += has_root ? w : 0u; if (STATS) leafp_t += (uint64_t)w * sr.w; }
+            const bool live = head && has_root && has_tips;
+            const uint32_t g = append_slot(live, &sh.n_groups);
+            if (live) {
+                hot[g] = (uint64_t)(sr.y & TILE_TIP_MASK) | ((uint64_t)(sr.z & TILE_TIP_MASK) << TILE_TIP_BITS) | ((uint64_t)w << (2 * TILE_TIP_BITS));
+                xs[g] = sr.x;
             }
         }
         {   // |M|, |M_root| (and the statistics) over the workgroup
@@ -2289,10 +2355,6 @@ __global__ __launch_bounds__(THREADS) void place_tile_kernel(DbDev db, PlacePara
             }
         }
         __syncthreads();
-        if (sh.overflow) {  // hand the read to the workspace kernel
-            if (tid == 0) spill_list[atomicAdd(spill_len, 1u)] = r;
-            continue;
-        }
         const uint32_t n_m = sh.n_m, n_root = sh.n_root, n_groups = sh.n_groups;
         uint32_t ib = ib_t;  // per thread; summed at the end
         auto finish_stats = [&]() {
@@ -2315,13 +2377,15 @@ __global__ __launch_bounds__(THREADS) void place_tile_kernel(DbDev db, PlacePara
             if ((uint64_t)n_root < exp_usize) { finish_stats(); record(CLS_UNCLASSIFIABLE_COVERAGE, (int32_t)n_root, 0, 0, 0); continue; }
         }
         // ---- C. descent ---------------------------------------------------------------------------------------------
-        int32_t iteration = 0;
-        for (;;) {
-            ++iteration;
-            if (iteration > prm.max_iterations) { record(CLS_ERR_MAX_ITER, 0, 0, (uint32_t)iteration, 0); break; }
-            const uint32_t fc = P.s[2], m = P.s[3];
-            const uint32_t a0 = P.s[0] + 1, a1 = P.s[6];  // first child = [a0, a1), second = [a1, end of the parent)
-            uint32_t c_ab = 0, c_both = 0;  // k-mers in a | in b << 16; in both (weights: at most 2 * nf < 2^16)
+        // Every thread owns the same entries at every level.  ONE pass per level: an entry is narrowed to the clade just
+        // chosen and, in the same breath, counted against the split of that clade's children; then one barrier for the
+        // three sums.  Both children's node records arrive a level ahead (one 64-byte scalar load per level), so the
+        // decision of a level starts the next pass at once.
+        snode_pair_t C = load_node_pair(db.nodes, P.s[2]);  // (a binary tree: the root has its two children in consecutive rows)
+        if (STATS && tid == 0) ib += 64;
+        uint32_t c_ab = 0, c_both = 0;  // k-mers in a | in b << 16; in both (weights: at most 2 * nf < 2^16)
+        {
+            const uint32_t a1 = P.s[6];
             for (uint32_t j = tid; j < n_groups; j += THREADS) {
                 const uint64_t h = hot[j];
                 const uint32_t lo_ = (uint32_t)h & TILE_TIP_MASK, hi_ = (uint32_t)(h >> TILE_TIP_BITS) & TILE_TIP_MASK, w = (uint32_t)(h >> (2 * TILE_TIP_BITS));
@@ -2329,6 +2393,13 @@ __global__ __launch_bounds__(THREADS) void place_tile_kernel(DbDev db, PlacePara
                 c_ab += (ina ? w : 0u) | ((inb ? w : 0u) << 16);
                 c_both += (ina && inb) ? w : 0u;
             }
+        }
+        int32_t iteration = 0;
+        for (;;) {
+            ++iteration;
+            if (iteration > prm.max_iterations) { record(CLS_ERR_MAX_ITER, 0, 0, (uint32_t)iteration, 0); break; }
+            const uint32_t m = P.s[3];
+            const uint32_t a0 = P.s[0] + 1, a1 = P.s[6];  // first child = [a0, a1), second = [a1, end of the parent)
             const uint32_t slot = (uint32_t)iteration % 3u;
             c_ab = wave_sum(c_ab); c_both = wave_sum(c_both);
             if (lane == 0) { if (c_ab) atomicAdd(&sh.cnt[slot][0], c_ab); if (c_both) atomicAdd(&sh.cnt[slot][1], c_both); }
@@ -2348,31 +2419,58 @@ __global__ __launch_bounds__(THREADS) void place_tile_kernel(DbDev db, PlacePara
                 break;
             }
             const bool right = only_b > only_a;
-            P = load_node(db.nodes, fc + (right ? 1u : 0u));
-            if (STATS && tid == 0) ib += 32;
-            if (P.s[3] == 0) {  // no non-LEAF child below the chosen clade (update_introspection_node.rs:45-85)
+            snode_t Pn;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) Pn.s[i] = right ? C.s[8 + i] : C.s[i];
+            if (Pn.s[3] == 0) {  // no non-LEAF child below the chosen clade (update_introspection_node.rs:45-85)
                 const uint32_t cn = right ? cnt_b : cnt_a, on = right ? only_b : only_a;
-                record(CLS_IDENTITY_FOUND, (int32_t)(rm ? on : cn), (int32_t)(rm ? U - cn : U - on), (uint32_t)iteration, ((uint64_t)P.s[5] << 32) | P.s[4]);
+                record(CLS_IDENTITY_FOUND, (int32_t)(rm ? on : cn), (int32_t)(rm ? U - cn : U - on), (uint32_t)iteration, ((uint64_t)Pn.s[5] << 32) | Pn.s[4]);
                 break;
             }
-            // narrow every entry to the chosen clade: one 8-byte split half for an entry with tips on both sides of a1
-            for (uint32_t j = tid; j < n_groups; j += THREADS) {
-                const uint64_t h = hot[j];
-                uint32_t lo_ = (uint32_t)h & TILE_TIP_MASK, hi_ = (uint32_t)(h >> TILE_TIP_BITS) & TILE_TIP_MASK;
-                const uint32_t w = (uint32_t)(h >> (2 * TILE_TIP_BITS));
-                const bool str = lo_ < a1 && hi_ >= a1 && (right || lo_ != a0);
-                bool gone;
-                if (str) {
-                    const uint2 t = ldx<uint2, ADDR32>(half, 2 * xs[j] + (right ? 1u : 0u));
-                    if (STATS) ib += 8;
-                    if (!right) hi_ = t.x; else lo_ = t.x;
-                    xs[j] = t.y;
+            C = load_node_pair(db.nodes, Pn.s[2]);  // its children: looked at after the next barrier
+            if (STATS && tid == 0) ib += 64;
+            // narrow every entry to the chosen clade (one 8-byte split half for an entry with tips on both sides of a1)
+            // and count it against the split of that clade's children
+            const uint32_t a1n = Pn.s[6];
+            c_ab = 0; c_both = 0;
+            for (uint32_t j0 = tid; j0 < n_groups; j0 += 4 * THREADS) {
+                uint64_t h[4];
+                uint32_t xv[4];
+                uint2 t[4];
+                bool str[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const uint32_t j = j0 + i * THREADS;
+                    h[i] = j < n_groups ? hot[j] : (uint64_t)TILE_TIP_MASK;  // beyond the end: the inactive entry {MAX, 0}, weight 0
                 }
-                if (!right) gone = lo_ >= a1 || lo_ == a0;   // no tip strictly below the first child
-                else gone = hi_ < a1 || lo_ == a1;           // nothing in the second child, or it is the tip itself
-                if (gone) { lo_ = TILE_TIP_MASK; hi_ = 0; }
-                if (str || gone) hot[j] = (uint64_t)lo_ | ((uint64_t)hi_ << TILE_TIP_BITS) | ((uint64_t)w << (2 * TILE_TIP_BITS));
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const uint32_t j = j0 + i * THREADS;
+                    const uint32_t lo_ = (uint32_t)h[i] & TILE_TIP_MASK, hi_ = (uint32_t)(h[i] >> TILE_TIP_BITS) & TILE_TIP_MASK;
+                    str[i] = lo_ < a1 && hi_ >= a1 && (right || lo_ != a0);
+                    xv[i] = str[i] ? xs[j] : 0u;
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    t[i] = ldx<uint2, ADDR32>(half, str[i] ? 2 * xv[i] + (right ? 1u : 0u) : 0u);  // (record 0: the dummy)
+                    if (STATS && str[i]) ib += 8;
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const uint32_t j = j0 + i * THREADS;
+                    uint32_t lo_ = (uint32_t)h[i] & TILE_TIP_MASK, hi_ = (uint32_t)(h[i] >> TILE_TIP_BITS) & TILE_TIP_MASK;
+                    const uint32_t w = (uint32_t)(h[i] >> (2 * TILE_TIP_BITS));
+                    if (str[i]) { if (!right) hi_ = t[i].x; else lo_ = t[i].x; xs[j] = t[i].y; }
+                    const bool gone = !right ? (lo_ >= a1 || lo_ == a0)    // no tip strictly below the first child
+                                             : (hi_ < a1 || lo_ == a1);    // nothing in the second child, or it is the tip itself
+                    if (gone) { lo_ = TILE_TIP_MASK; hi_ = 0; }
+                    if ((str[i] || gone) && j < n_groups) hot[j] = (uint64_t)lo_ | ((uint64_t)hi_ << TILE_TIP_BITS) | ((uint64_t)w << (2 * TILE_TIP_BITS));
+                    const bool ina = lo_ < a1n, inb = hi_ >= a1n;
+                    c_ab += (ina ? w : 0u) | ((inb ? w : 0u) << 16);
+                    c_both += (ina && inb) ? w : 0u;
+                }
             }
+            P = Pn;
         }
         finish_stats();
     }
@@ -2452,6 +2550,7 @@ int order_key_bits(const DbDev& db) {  // + 1: reads without a key sort last wit
 }
 constexpr int CLS_SLOTS[N_CLASSES] = {5, 16};      // k-mers per read: 320 / 1024
 constexpr int CLS_SET_BITS[N_CLASSES] = {9, 11};   // LDS distinct-hit set: 512 / 2048 entries
+constexpr int NARROW_CANON_BITS = CLS_NARROW_CANON_BITS;
 
 bool use_fast(const DbDev& db);
 bool use_order(const DbDev& db, uint32_t n_reads) {
@@ -2463,6 +2562,8 @@ bool use_fast(const DbDev& db) {
     return db.format == FMT_SPLIT && (db.binary_tree || db.max_nonleaf_arity <= FAST_MAX_ARITY) && front && !tuning().no_fast;
 }
 int fast_mode(const DbDev& db) { return db.direct == nullptr ? 2 : db.canonical ? 1 : 0; }
+// table bits of a wave-per-read class: the narrow class needs fewer on a strand-symmetric index (one lookup per window)
+int set_bits_of(const DbDev& db, int c) { return (c == 0 && use_fast(db) && fast_mode(db) == 1) ? NARROW_CANON_BITS : CLS_SET_BITS[c]; }
 // the LDS-tiled long-read kernel: binary FMT_SPLIT index with a direct table, pre-order indices in 24 bits
 bool use_tile(const DbDev& db) {
     return db.format == FMT_SPLIT && db.binary_tree && db.direct != nullptr && db.n_nodes < TILE_TIP_MASK && !tuning().no_tile;
@@ -2480,7 +2581,7 @@ size_t smem_of(const DbDev& db, int c) {
     if (use_fast(db)) {
         const uint32_t ac = ascii_cap_of(db, c);
         const uint32_t packed = db.direct ? 4u * (((ac >> 4) + 2 + 3) & ~3u) : 0u;
-        return (size_t)WAVES_PER_BLOCK * (ac + packed + (12u << CLS_SET_BITS[c]) + (db.binary_tree ? 0u : 12u * FAST_MAX_ARITY + 16u));
+        return (size_t)WAVES_PER_BLOCK * (ac + packed + (12u << set_bits_of(db, c)) + (db.binary_tree ? 0u : 12u * FAST_MAX_ARITY + 16u));
     }
     return (size_t)WAVES_PER_BLOCK * (seq_cap_of(db, c) + (4u << CLS_SET_BITS[c]) + 4u * 64 * CLS_SLOTS[c]) +
            (child_in_lds(db) ? (size_t)WAVES_PER_BLOCK * 2 * child_ws_stride(db) * 4 : 0);
@@ -2507,6 +2608,7 @@ const void* kernel_of_t(const DbDev& db, bool stats) {
     return binary ? (const void*)place_wave_kernel<SLOTS, SET_BITS, false, true> : (const void*)place_wave_kernel<SLOTS, SET_BITS, false, false>;
 }
 const void* kernel_of(const DbDev& db, int c, bool stats) {
+    if (c == 0 && set_bits_of(db, 0) != CLS_SET_BITS[0]) return kernel_of_t<CLS_SLOTS[0], NARROW_CANON_BITS>(db, stats);
     return c == 0 ? kernel_of_t<CLS_SLOTS[0], CLS_SET_BITS[0]>(db, stats) : kernel_of_t<CLS_SLOTS[1], CLS_SET_BITS[1]>(db, stats);
 }
 
@@ -2523,7 +2625,7 @@ size_t blk_smem(const DbDev& db) {
 }  // namespace
 
 std::string dominant_kernel_name(const DbDev& db, bool stats, const PlacePlan* plan) {
-    const std::string sl = std::to_string(CLS_SLOTS[0]) + ", " + std::to_string(CLS_SET_BITS[0]) + ", " + (stats ? "true" : "false");
+    const std::string sl = std::to_string(CLS_SLOTS[0]) + ", " + std::to_string(set_bits_of(db, 0)) + ", " + (stats ? "true" : "false");
     auto b = [](bool v) { return std::string(v ? "true" : "false"); };
     if (plan && plan->grid_tile)  // a launch provisioned for long reads: the LDS-tiled kernel is the one that is timed
         return "place_tile_kernel<" + std::to_string(plan->tile_threads) + ", " + b(db.canonical != 0) + ", " + b(stats) + ", " + b(db.addr32 != 0) + ">";
@@ -2732,7 +2834,8 @@ hipError_t launch_place(const DbDev& db, const PlaceParams& prm, const PlacePlan
     // else the wave-per-read kernel of the <= 320-k-mer class
     const bool time_tile = plan.grid_tile != 0;
     if (ev_start && !time_tile) (void)hipEventRecord(ev_start, stream);
-    launch_class(std::integral_constant<int, CLS_SLOTS[0]>{}, std::integral_constant<int, CLS_SET_BITS[0]>{}, 0);
+    if (set_bits_of(db, 0) != CLS_SET_BITS[0]) launch_class(std::integral_constant<int, CLS_SLOTS[0]>{}, std::integral_constant<int, NARROW_CANON_BITS>{}, 0);
+    else launch_class(std::integral_constant<int, CLS_SLOTS[0]>{}, std::integral_constant<int, CLS_SET_BITS[0]>{}, 0);
     if (ev_stop && !time_tile) (void)hipEventRecord(ev_stop, stream);
     if (hipGetLastError() != hipSuccess) return hipErrorLaunchFailure;
     launch_class(std::integral_constant<int, CLS_SLOTS[1]>{}, std::integral_constant<int, CLS_SET_BITS[1]>{}, 1);

@@ -17,7 +17,8 @@ from . import _abi
 from .flatdb import FlatDb
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libclsplace.so")
+# (CLS_PLACE_LIB: an experiment build of the same library, tools/build_variant.sh)
+LIB_PATH = os.environ.get("CLS_PLACE_LIB") or os.path.join(_HERE, "csrc", "libclsplace.so")
 _LIB = None
 
 EXPORTS = [

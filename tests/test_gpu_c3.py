@@ -99,3 +99,22 @@ def test_async_calls_on_one_stream_share_one_scratch_slot(c3):
     assert db.refresh_info().scratch_slots <= 8
     for o in outs:
         assert len(records_equal(o.cpu().numpy().view(_abi.PLACEMENT_DTYPE), ref)) == 0
+
+
+@pytest.mark.parametrize("config", ["C3s12", "C3s35"])
+def test_shipped_shapes_parity_sample(config):
+    """The shapes the reference actually ships, at bench size: the 10 000-leaf tree with low-support branches collapsed
+    into polytomies (`cls build-db -s 70`, tree.rs:248-285) at k = 12 and at the reference's default k = 35 / m = 4
+    (docs/book/02-build-db.md:109-129).  A 40 k-read sample of the bench's stream against the oracle, both values of
+    remove_intersection; `bench.py --config C3s12|C3s35` measures the same indexes."""
+    cfg = CONFIGS[config]
+    s = SynthDb(cfg["n_leaves"], cfg["ref_len"], cfg["k_size"], cfg["m_size"], collapse_prob=cfg["collapse_prob"])
+    bases, offsets, _ = s.reads(40_000, 150, seed=3, first=0)
+    oracle = op.OraclePort(s.flat)
+    with engine.PlacementDb(s.flat, device=0) as db:
+        assert db.info.binary_tree == 0 and db.info.format == 1 and db.info.direct_table == (2 if cfg["k_size"] <= 15 else 0)
+        for kw in (dict(), dict(remove_intersection=True)):
+            got, gst = device_place(db, bases, offsets, engine.make_params(**kw))
+            want, wst = oracle.place_batch(bases, offsets, op.make_params(**kw), threads=16, want_stats=True)
+            _compare(got, gst, want, wst, f"{config} {kw}")
+    oracle.close()
