@@ -125,7 +125,7 @@ class DbInfo(C.Structure):
         ("direct_table", C.c_uint32),
         ("n_tip_sets", C.c_uint32),
         ("scratch_slots", C.c_uint32),
-        ("pad_", C.c_uint32),
+        ("fat_direct_table", C.c_uint32),
     ]
 
 

@@ -91,6 +91,7 @@ struct cls_db {
     void* d_postings = nullptr;
     void* d_bucket_key = nullptr;
     void* d_direct = nullptr;
+    void* d_direct16 = nullptr;
     void* d_sets = nullptr;
     std::mutex ws_mu;
     uint64_t max_read_len = 0;  // what the device-buffer entry provisions its long-read slices for (0: none, reads of up to
@@ -114,7 +115,7 @@ namespace {
 struct Knob { const char* name; int cls::Tuning::*field; };
 const Knob KNOBS[] = {
     {"no_fast", &cls::Tuning::no_fast}, {"no_order", &cls::Tuning::no_order}, {"force_list", &cls::Tuning::force_list},
-    {"no_tile", &cls::Tuning::no_tile}, {"tile_pass_codes", &cls::Tuning::tile_pass_codes}, {"blocks_per_cu", &cls::Tuning::blocks_per_cu}, {"key_blocks_per_cu", &cls::Tuning::key_blocks_per_cu},
+    {"no_fat_direct", &cls::Tuning::no_fat_direct}, {"no_tile", &cls::Tuning::no_tile}, {"tile_pass_codes", &cls::Tuning::tile_pass_codes}, {"blocks_per_cu", &cls::Tuning::blocks_per_cu}, {"key_blocks_per_cu", &cls::Tuning::key_blocks_per_cu},
     {"long_blocks_per_cu", &cls::Tuning::long_blocks_per_cu}, {"order_mode", &cls::Tuning::order_mode},
     {"order_windows", &cls::Tuning::order_windows}, {"order_both_strands", &cls::Tuning::order_both_strands},
     {"order_block_shift", &cls::Tuning::order_block_shift}, {"order_sample_shift", &cls::Tuning::order_sample_shift},
@@ -170,6 +171,7 @@ extern "C" void cls_db_destroy(cls_db* db) {
     if (db->d_postings) (void)hipFree(db->d_postings);
     if (db->d_bucket_key) (void)hipFree(db->d_bucket_key);
     if (db->d_direct) (void)hipFree(db->d_direct);
+    if (db->d_direct16) (void)hipFree(db->d_direct16);
     if (db->d_sets) (void)hipFree(db->d_sets);
     if (have_prev) (void)hipSetDevice(prev);
     delete db;
@@ -206,6 +208,7 @@ extern "C" int cls_db_create(const cls_db_desc* d, int device, cls_db** out) {
             (e = up(&db->d_postings, E.postings.data(), E.postings.size() * 4)) != hipSuccess ||
             (e = up(&db->d_bucket_key, E.bucket_key.data(), E.bucket_key.size() * 8)) != hipSuccess ||
             (!E.direct.empty() && (e = up(&db->d_direct, E.direct.data(), E.direct.size() * 4)) != hipSuccess) ||
+            (!E.direct16.empty() && (e = up(&db->d_direct16, E.direct16.data(), E.direct16.size() * 4)) != hipSuccess) ||
             (!E.sets.empty() && (e = up(&db->d_sets, E.sets.data(), E.sets.size() * sizeof(cls::SetRec))) != hipSuccess)) {
             cls_db_destroy(db);
             return fail(e == hipErrorOutOfMemory ? CLS_E_NOMEM : CLS_E_HIP, std::string("cls_db_create: upload failed: ") + hipGetErrorString(e));
@@ -216,6 +219,7 @@ extern "C" int cls_db_create(const cls_db_desc* d, int device, cls_db** out) {
         v.postings = (const uint32_t*)db->d_postings;
         v.bucket_key = (const uint64_t*)db->d_bucket_key;
         v.direct = (const uint32_t*)db->d_direct;
+        v.direct16 = (const uint32_t*)db->d_direct16;
         v.sets = (const cls::SetRec*)db->d_sets;
         v.table_mask = E.table.size() - 1;
         v.n_nodes = (uint32_t)E.nodes.size();
@@ -241,13 +245,14 @@ extern "C" int cls_db_create(const cls_db_desc* d, int device, cls_db** out) {
         i.n_closed_kmers = E.n_closed;
         i.table_slots = E.table.size();
         i.postings_words = E.postings.size();
-        i.hbm_bytes = E.nodes.size() * sizeof(cls::DNode) + E.table.size() * sizeof(cls::Slot) + E.postings.size() * 4 + E.bucket_key.size() * 8 + E.direct.size() * 4 + E.sets.size() * sizeof(cls::SetRec);
+        i.hbm_bytes = E.nodes.size() * sizeof(cls::DNode) + E.table.size() * sizeof(cls::Slot) + E.postings.size() * 4 + E.bucket_key.size() * 8 + E.direct.size() * 4 + E.direct16.size() * 4 + E.sets.size() * sizeof(cls::SetRec);
         i.max_read_kmers = (uint32_t)std::max<uint64_t>(cls::MAX_READ_KMERS, 2 * db->max_read_len);
         i.device = device;
         i.format = E.format;
         i.binary_tree = E.strictly_binary ? 1u : 0u;
         i.direct_table = E.direct.empty() ? 0u : (E.canonical ? 2u : 1u);
         i.n_tip_sets = (uint32_t)E.n_sets;
+        i.fat_direct_table = E.direct16.empty() ? 0u : 1u;
         *out = db;
         return CLS_OK;
     } catch (const std::bad_alloc&) {

@@ -550,6 +550,17 @@ int encode_db(const cls_db_desc* d, EncodedDb& E, std::string& err) {
                 }
             });
             E.canonical = !asym.load();
+            if (K <= FAT_DIRECT_MAX_K && !tuning().no_fat_direct) {  // the denormalised copy for the wave-per-read kernels
+                E.direct16.resize(4 * n_codes);
+                parallel_chunks(n_codes, nt, [&](unsigned, uint64_t lo, uint64_t hi) {
+                    for (uint64_t code = lo; code < hi; ++code) {
+                        const uint32_t e = E.direct[code];
+                        const SetRec& sr = E.sets[e & SET_ID_MASK];  // (set 0: {0, MAX, 0, 0})
+                        uint32_t* o = &E.direct16[4 * code];
+                        o[0] = sr.x; o[1] = sr.vlo_lg; o[2] = sr.vhi_root; o[3] = e;
+                    }
+                });
+            }
         }
     }
     lap("direct table");

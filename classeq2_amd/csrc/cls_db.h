@@ -46,6 +46,7 @@ struct EncodedDb {
     std::vector<uint64_t> bucket_key;
     HugeVec<SetRec> sets;             // FMT_SPLIT: tip sets (entry 0 = "no such k-mer")
     HugeVec<uint32_t> direct;         // 4^k set ids (FMT_SPLIT, k <= DIRECT_MAX_K) or empty
+    HugeVec<uint32_t> direct16;       // 4^k x 4 words: set record + set id (k <= FAT_DIRECT_MAX_K) or empty
     uint32_t k = 0, m = 0, m_eff = 0;
     uint32_t max_depth = 0, max_nonleaf_arity = 0;
     uint64_t n_kmers = 0, n_closed = 0;

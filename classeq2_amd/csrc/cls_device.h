@@ -95,6 +95,11 @@ struct SetRec {
 };
 static_assert(sizeof(SetRec) == 16, "SetRec");
 constexpr uint32_t DIRECT_MAX_K = 15;
+// For small k the direct table is also kept DENORMALISED: 16-byte entries {root split x, first tip | lg << 27,
+// last tip | has_root << 31, set id | tier << 30} = the set record with the set id in place of n_leaf, so that the
+// wave-per-read kernels get a k-mer's whole initial descent state from ONE read instead of two dependent ones
+// (table entry -> set record).  4^12 entries = 268 MB; the 4-byte table stays (locality keys, long reads).
+constexpr uint32_t FAT_DIRECT_MAX_K = 12;
 constexpr uint32_t DIRECT_TIP_BITS = 27;
 constexpr uint32_t DIRECT_TIP_MASK = (1u << DIRECT_TIP_BITS) - 1;
 struct TipRec {
@@ -113,6 +118,7 @@ struct DbDev {
     const uint32_t* postings;   // FMT_LIST: u32 words; FMT_SPLIT: TipRec split records (16-byte units)
     const uint64_t* bucket_key;
     const uint32_t* direct;     // FMT_SPLIT, k <= DIRECT_MAX_K: 4^k set ids, or nullptr
+    const uint32_t* direct16;   // k <= FAT_DIRECT_MAX_K: the same table with the set record inside the entry (below), or nullptr
     const SetRec* sets;         // FMT_SPLIT: tip sets
     uint64_t table_mask;
     uint32_t n_nodes;

@@ -990,10 +990,13 @@ constexpr uint32_t FAST_MAX_ARITY = 256;  // non-LEAF children per clade the fas
 // `canonical`: one lookup per window j < nk = nf, of the smaller of the k-mer and its reverse complement;
 // kw = how many distinct query k-mers the lookup stands for (2, or 1 for a palindrome).
 // Returns false if the read holds a character other than ACGT.
-template <int SLOTS, int SET_BITS, bool ADDR32>
+// FAT: the entry comes from the denormalised 16-byte table (`direct16`) together with its set record `rec` =
+// {root split, first tip | lg << 27, last tip | has_root << 31}: no second, dependent read.
+struct FatRec { uint32_t x, vlo_lg, vhi_root; };
+template <int SLOTS, int SET_BITS, bool ADDR32, bool FAT = false>
 __device__ __forceinline__ bool fast_front(const DbDev& db, const FastCtx& cx, const uint8_t* __restrict__ bases, uint64_t b0,
                                            uint32_t L, uint32_t nf, uint32_t nk, uint32_t (&e)[SLOTS], uint32_t (&key)[SLOTS], uint32_t (&kw)[SLOTS],
-                                           uint32_t sample_shift = 32, bool canonical = false, uint32_t table_bits = SET_BITS) {
+                                           FatRec (&rec)[SLOTS], uint32_t sample_shift = 32, bool canonical = false, uint32_t table_bits = SET_BITS) {
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t k = db.k;
     bool bad = false;
@@ -1047,8 +1050,14 @@ __device__ __forceinline__ bool fast_front(const DbDev& db, const FastCtx& cx, c
         // sample_shift < 32: look up only the k-mers whose scrambled code has its top bits clear (a content-
         // based sample, the same k-mers in every read that contains them); 32 = all
         const bool take = valid && (sample_shift >= 32 || ((code * 0x9E3779B1u) >> sample_shift) == 0);
-        const uint32_t v = ldx<uint32_t, ADDR32>(direct, take ? code : 0u);
-        e[s] = take ? v : 0u;
+        if constexpr (FAT) {
+            const uint4 v = ldx<uint4, ADDR32>(reinterpret_cast<const uint4*>(db.direct16), take ? code : 0u);
+            e[s] = take ? v.w : 0u;
+            rec[s] = FatRec{v.x, take ? v.y : 0xFFFFFFFFu, take ? v.z : 0u};
+        } else {
+            const uint32_t v = ldx<uint32_t, ADDR32>(direct, take ? code : 0u);
+            e[s] = take ? v : 0u;
+        }
         key[s] = code;
         kw[s] = !take ? 0u : (canonical && !palindrome) ? 2u : 1u;  // canonical: the window stands for the k-mer and its reverse complement
     }
@@ -1384,9 +1393,12 @@ __device__ __forceinline__ void place_read_fast(const DbDev& db, const PlacePara
     // CANON (an index in which every k-mer and its reverse complement carry the same tip set, i.e. one built from
     // both strands): the k-mers of window p on the two strands are reverse complements of each other, so ONE lookup
     // of the smaller of the two answers for both; half the lookups, half the slots.
-    constexpr bool CANON = MODE == 1, HASHED = MODE == 2;  // MODE 0: direct table, both strands looked up
+    // MODE 0: direct table, both strands looked up; 1: strand-symmetric index, one lookup per window; 2: MurmurHash3 front;
+    // 3 / 4: as 0 / 1 through the denormalised 16-byte table (k <= 12): the set record comes with the entry
+    constexpr bool CANON = MODE == 1 || MODE == 4, HASHED = MODE == 2, FAT = MODE >= 3;
     constexpr int LS = CANON ? (SLOTS + 1) / 2 : SLOTS;
     uint32_t sid[LS], key[LS], kw[LS];
+    FatRec frec[LS];
     // the wide class sizes its LDS tables by the read (clearing 3 x 2048 entries cost more than placing a 250 bp read)
     uint32_t tb = SET_BITS;
     if constexpr (SET_BITS > 9) {
@@ -1399,8 +1411,8 @@ __device__ __forceinline__ void place_read_fast(const DbDev& db, const PlacePara
     uint32_t ib = 0;  // STATS: index bytes this lane asked for (table entries, set records, node records, split halves)
     if constexpr (HASHED) valid_read = hash_front<LS, SET_BITS, ADDR32>(db, cx, bases, b0, L, nf, nk, sid, key, kw, tb, ib);
     else {
-        valid_read = fast_front<LS, SET_BITS, ADDR32>(db, cx, bases, b0, L, nf, CANON ? nf : nk, sid, key, kw, 32, CANON, tb);
-        if (STATS) for (int s = 0; s < LS; ++s) ib += kw[s] ? 4u : 0u;  // one 4-byte table entry per looked-up window
+        valid_read = fast_front<LS, SET_BITS, ADDR32, FAT>(db, cx, bases, b0, L, nf, CANON ? nf : nk, sid, key, kw, frec, 32, CANON, tb);
+        if (STATS) for (int s = 0; s < LS; ++s) ib += kw[s] ? (FAT ? 16u : 4u) : 0u;  // one table entry per looked-up window
     }
     // cls_query_stats.index_bytes: written last, after the counters (put_stats clears the field)
     auto put_index_bytes = [&]() {
@@ -1473,8 +1485,14 @@ __device__ __forceinline__ void place_read_fast(const DbDev& db, const PlacePara
         for (int i = 0; i < G; ++i) {
             const int s = g0 + i;
             const bool own = s < LS && ((owner >> s) & 1u);
-            sr[i] = ldx<uint4, ADDR32>(sets, own ? sid[s < LS ? s : 0] : 0u);  // set 0: {0, MAX, 0, 0}
-            if (STATS && own) ib += 16;
+            if constexpr (FAT) {  // the record came with the table entry (n_leaf, a statistic, still lives in the set record)
+                const FatRec fr = frec[s < LS ? s : 0];
+                sr[i] = own ? uint4{fr.x, fr.vlo_lg, fr.vhi_root, 0u} : uint4{0u, 0xFFFFFFFFu, 0u, 0u};
+                if (STATS && own) sr[i].w = ldx<uint4, ADDR32>(sets, sid[s < LS ? s : 0]).w;
+            } else {
+                sr[i] = ldx<uint4, ADDR32>(sets, own ? sid[s < LS ? s : 0] : 0u);  // set 0: {0, MAX, 0, 0}
+                if (STATS && own) ib += 16;
+            }
         }
 #pragma unroll
         for (int i = 0; i < G; ++i) {
@@ -1524,7 +1542,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, SLOTS <= 5 ? FAST_MIN_WAVES :
     const uint32_t packed_words = MODE == 2 ? 0u : ((ascii_cap >> 4) + 2 + 3) & ~3u;  // whole 16-byte units: what follows stays 16-byte aligned
     // the staging area must fit over the three tables (combinations that do not are instantiated by the dispatch
     // macros but never launched: set_bits_of)
-    constexpr bool FITS = (12u << SET_BITS) >= 16u * 64 * (MODE == 1 ? (SLOTS + 1) / 2 : SLOTS);
+    constexpr bool FITS = (12u << SET_BITS) >= 16u * 64 * ((MODE == 1 || MODE == 4) ? (SLOTS + 1) / 2 : SLOTS);
     if constexpr (FITS) {
     const uint32_t per_wave = ascii_cap + 4u * packed_words + (12u << SET_BITS) + (POLY ? 12u * FAST_MAX_ARITY + 16u : 0u);
     FastCtx cx;
@@ -1617,7 +1635,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void order_key_kernel(DbDev d
             // (without a direct table FWD means "the forward k-mers only": the key then depends on the strand read)
             uint32_t ib_unused = 0;
             if constexpr (HASHED) valid_read = hash_front<LS, 0, ADDR32>(db, cx, bases, b0, L, nf, FWD ? nf : nk, e, code, kw, 0, ib_unused);
-            else valid_read = fast_front<LS, 0, ADDR32>(db, cx, bases, b0, L, nf, FWD ? nf : nk, e, code, kw, sample_shift, FWD);
+            else { FatRec unused[LS]; valid_read = fast_front<LS, 0, ADDR32>(db, cx, bases, b0, L, nf, FWD ? nf : nk, e, code, kw, unused, sample_shift, FWD); }
             if (valid_read) {
                 uint32_t cand = 0, n_cand = 0;
                 for (uint32_t tier = 0; tier < 4 && n_cand < 4; ++tier) {
@@ -2561,9 +2579,10 @@ bool use_fast(const DbDev& db) {
     const bool front = db.direct != nullptr || (db.addr32 && db.k <= 256);
     return db.format == FMT_SPLIT && (db.binary_tree || db.max_nonleaf_arity <= FAST_MAX_ARITY) && front && !tuning().no_fast;
 }
-int fast_mode(const DbDev& db) { return db.direct == nullptr ? 2 : db.canonical ? 1 : 0; }
+int fast_mode(const DbDev& db) { return db.direct == nullptr ? 2 : (db.direct16 && db.addr32) ? (db.canonical ? 4 : 3) : db.canonical ? 1 : 0; }
+bool mode_canonical(int mode) { return mode == 1 || mode == 4; }
 // table bits of a wave-per-read class: the narrow class needs fewer on a strand-symmetric index (one lookup per window)
-int set_bits_of(const DbDev& db, int c) { return (c == 0 && use_fast(db) && fast_mode(db) == 1) ? NARROW_CANON_BITS : CLS_SET_BITS[c]; }
+int set_bits_of(const DbDev& db, int c) { return (c == 0 && use_fast(db) && mode_canonical(fast_mode(db))) ? NARROW_CANON_BITS : CLS_SET_BITS[c]; }
 // the LDS-tiled long-read kernel: binary FMT_SPLIT index with a direct table, pre-order indices in 24 bits
 bool use_tile(const DbDev& db) {
     return db.format == FMT_SPLIT && db.binary_tree && db.direct != nullptr && db.n_nodes < TILE_TIP_MASK && !tuning().no_tile;
@@ -2594,6 +2613,8 @@ const void* kernel_of_t(const DbDev& db, bool stats) {
 #define CLS_FAST_OF2(A32, MD) (db.binary_tree ? CLS_FAST_OF(A32, MD, false) : CLS_FAST_OF(A32, MD, true))
         const int mode = fast_mode(db);
         if (mode == 2) return CLS_FAST_OF2(true, 2);  // (the hashed front is only instantiated with 32-bit offsets: use_fast)
+        if (mode == 3) return CLS_FAST_OF2(true, 3);  // (the 16-byte table only exists for k <= 12: 32-bit offsets)
+        if (mode == 4) return CLS_FAST_OF2(true, 4);
         if (db.addr32) return mode == 1 ? CLS_FAST_OF2(true, 1) : CLS_FAST_OF2(true, 0);
         return mode == 1 ? CLS_FAST_OF2(false, 1) : CLS_FAST_OF2(false, 0);
 #undef CLS_FAST_OF2
@@ -2807,6 +2828,8 @@ hipError_t launch_place(const DbDev& db, const PlaceParams& prm, const PlacePlan
 #define CLS_LAUNCH_FAST3(ST, A32, MD) do { if (db.binary_tree) CLS_LAUNCH_FAST(ST, A32, MD, false); else CLS_LAUNCH_FAST(ST, A32, MD, true); } while (0)
 #define CLS_LAUNCH_FAST2(ST, A32) do { if (db.canonical) CLS_LAUNCH_FAST3(ST, A32, 1); else CLS_LAUNCH_FAST3(ST, A32, 0); } while (0)
             if (fast_mode(db) == 2) { if (st) CLS_LAUNCH_FAST3(true, true, 2); else CLS_LAUNCH_FAST3(false, true, 2); }
+            else if (fast_mode(db) == 3 && db.addr32) { if (st) CLS_LAUNCH_FAST3(true, true, 3); else CLS_LAUNCH_FAST3(false, true, 3); }
+            else if (fast_mode(db) == 4 && db.addr32) { if (st) CLS_LAUNCH_FAST3(true, true, 4); else CLS_LAUNCH_FAST3(false, true, 4); }
             else if (db.addr32) { if (st) CLS_LAUNCH_FAST2(true, true); else CLS_LAUNCH_FAST2(false, true); }
             else { if (st) CLS_LAUNCH_FAST2(true, false); else CLS_LAUNCH_FAST2(false, false); }
 #undef CLS_LAUNCH_FAST2

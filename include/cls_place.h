@@ -192,7 +192,7 @@ typedef struct cls_db_info {
     uint32_t n_tip_sets;       /* format 1: distinct tip lists (k-mers with the same one share a split tree) */
     uint32_t scratch_slots;    /* per-call scratch workspaces the handle holds right now (a caller that pipelines
                                 * batches on ONE stream keeps one; at most 8) */
-    uint32_t pad_;
+    uint32_t fat_direct_table; /* 1: k <= 12, the direct table is also kept with the set record inside its 16-byte entries */
 } cls_db_info;
 
 /* Number of usable HIP devices (0 if none). */

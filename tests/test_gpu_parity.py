@@ -350,3 +350,26 @@ def test_long_reads_lds_tiled_kernel_and_its_spill_path():
         assert len(records_equal(got, want[("sym", ())])) == 0
     finally:
         engine.set_tuning("no_tile", 0)
+
+
+@pytest.mark.parametrize("k,collapse,trunc", [(12, 0.0, False), (10, 0.4, False), (11, 0.0, True)])
+def test_slim_and_denormalised_direct_tables_agree(k, collapse, trunc):
+    """For k <= 12 the wave-per-read kernels read a denormalised 16-byte direct table (set record inside the entry);
+    with the knob off they go through the 4-byte table + set records like every larger k.  Both against the oracle,
+    narrow and wide class, locality-ordered batch."""
+    s = SynthDb(300, 900, k, 4, collapse_prob=collapse)
+    flat = truncate_random_sets(s.flat, 0.05, seed=6) if trunc else s.flat
+    rng = np.random.default_rng(23)
+    bases, offsets = ragged_reads(rng, s, 5000, 60, 480, lower_frac=0.02)
+    with engine.PlacementDb(flat, device=0) as db:
+        assert db.info.fat_direct_table == 1
+    for kw in (dict(), dict(remove_intersection=True)):
+        _check(flat, bases, offsets, kw, threads=16)
+    engine.set_tuning("no_fat_direct", 1)
+    try:
+        with engine.PlacementDb(flat, device=0) as db:
+            assert db.info.fat_direct_table == 0
+        for kw in (dict(), dict(remove_intersection=True)):
+            _check(flat, bases, offsets, kw, threads=16)
+    finally:
+        engine.set_tuning("no_fat_direct", 0)
