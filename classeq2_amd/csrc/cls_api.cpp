@@ -87,6 +87,7 @@ struct cls_db {
     cls::DbDev dev{};
     cls_db_info info{};
     void* d_nodes = nullptr;
+    void* d_kids = nullptr;
     void* d_table = nullptr;
     void* d_postings = nullptr;
     void* d_bucket_key = nullptr;
@@ -167,6 +168,7 @@ extern "C" void cls_db_destroy(cls_db* db) {
         for (void* p : {c.d_bases, c.d_off, c.d_out, c.d_stats}) if (p) (void)hipFree(p);
     }
     if (db->d_nodes) (void)hipFree(db->d_nodes);
+    if (db->d_kids) (void)hipFree(db->d_kids);
     if (db->d_table) (void)hipFree(db->d_table);
     if (db->d_postings) (void)hipFree(db->d_postings);
     if (db->d_bucket_key) (void)hipFree(db->d_bucket_key);
@@ -204,6 +206,7 @@ extern "C" int cls_db_create(const cls_db_desc* d, int device, cls_db** out) {
         };
         hipError_t e;
         if ((e = up(&db->d_nodes, E.nodes.data(), E.nodes.size() * sizeof(cls::DNode))) != hipSuccess ||
+            (e = up(&db->d_kids, E.kids.data(), E.kids.size() * 4)) != hipSuccess ||
             (e = up(&db->d_table, E.table.data(), E.table.size() * sizeof(cls::Slot))) != hipSuccess ||
             (e = up(&db->d_postings, E.postings.data(), E.postings.size() * 4)) != hipSuccess ||
             (e = up(&db->d_bucket_key, E.bucket_key.data(), E.bucket_key.size() * 8)) != hipSuccess ||
@@ -215,6 +218,7 @@ extern "C" int cls_db_create(const cls_db_desc* d, int device, cls_db** out) {
         }
         cls::DbDev& v = db->dev;
         v.nodes = (const cls::DNode*)db->d_nodes;
+        v.kids = (const uint32_t*)db->d_kids;
         v.table = (const cls::Slot*)db->d_table;
         v.postings = (const uint32_t*)db->d_postings;
         v.bucket_key = (const uint64_t*)db->d_bucket_key;

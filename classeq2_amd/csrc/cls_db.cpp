@@ -178,6 +178,12 @@ int encode_db(const cls_db_desc* d, EncodedDb& E, std::string& err) {
         E.max_depth = depth;
         for (uint32_t r = 0; r < N; ++r) leaf_by_pre[E.nodes[r].pre] = d->nodes[order[r]].kind == CLS_KIND_LEAF;
     }
+    E.kids.assign(4 * (size_t)N, 0);
+    for (uint32_t r = 0; r < N; ++r) {
+        const DNode& n = E.nodes[r];
+        const uint32_t nc = d->nodes[order[r]].n_children;
+        for (uint32_t j = 2; j < 5; ++j) E.kids[4 * (size_t)r + (j - 2)] = j < nc ? E.nodes[n.first_child + j].pre : n.pre + n.size;
+    }
     // ---- 3. clade id -> pre ------------------------------------------------------
     std::vector<std::pair<uint64_t, uint32_t>> id2pre(N);
     for (uint32_t r = 0; r < N; ++r) id2pre[r] = {E.nodes[r].id, E.nodes[r].pre};

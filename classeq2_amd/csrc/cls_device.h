@@ -114,6 +114,9 @@ enum : uint32_t { FMT_LIST = 0, FMT_SPLIT = 1 };
 
 struct DbDev {
     const DNode* nodes;
+    const uint32_t* kids;       // per node row 4 words {start of the 3rd child, of the 4th, of the 5th, 0} in pre-order space (the end
+                                // of the clade where it has fewer children): with DNode.pre / .split the boundaries of up to four
+                                // non-LEAF children, so that a small polytomy is scored from two scalar loads
     const Slot* table;          // FMT_LIST: Slot; FMT_SPLIT: TSlot (same size, same probe sequence)
     const uint32_t* postings;   // FMT_LIST: u32 words; FMT_SPLIT: TipRec split records (16-byte units)
     const uint64_t* bucket_key;

@@ -961,6 +961,17 @@ __device__ __forceinline__ snode_t load_node(const DNode* nodes, uint32_t row) {
     return r;
 }
 
+// Where the third, fourth and fifth child of a clade start (DbDev.kids): 16 bytes through the scalar unit.
+struct skids_t { uint32_t s[4]; };
+__device__ __forceinline__ skids_t load_kids(const uint32_t* kids, uint32_t row) {
+    typedef __attribute__((address_space(4))) const uint32_t as4_u32;
+    as4_u32* p = (as4_u32*)(uintptr_t)(kids + 4 * (size_t)__builtin_amdgcn_readfirstlane(row));
+    skids_t r;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r.s[i] = p[i];
+    return r;
+}
+
 // Indexed load off a wave-uniform base.  ADDR32: the byte offset is known to fit 32 bits (arrays below
 // 4 GiB), which lets the compiler use the SGPR-base + 32-bit-VGPR-offset form instead of building a 64-bit
 // address pair per access (each pair costs an extra VGPR holding the zero high half).
@@ -1162,6 +1173,8 @@ __device__ __forceinline__ void descend_groups(const DbDev& db, const PlaceParam
     // ---- C. descent -----------------------------------------------------------------------------------
     const uint32_t* __restrict__ half = db.postings;  // record x = 8-byte halves 2x (left part), 2x+1 (right part)
     const bool rm = prm.remove_intersection != 0;
+    skids_t K{};  // polytomy trees: where the current clade's third .. fifth child start, fetched with its node record
+    if (POLY) K = load_kids(db.kids, 0);
     int32_t iteration = 0;
     for (;;) {
         ++iteration;
@@ -1174,58 +1187,103 @@ __device__ __forceinline__ void descend_groups(const DbDev& db, const PlaceParam
             // children's intervals, then one 8-byte read per further occupied child), adding its weight to the
             // per-child counters in LDS.  Cost per group = children it has tips under, whatever the clade's arity.
             const DNode* __restrict__ nodes = db.nodes;
-            uint32_t last_end = 0;
-            if (m) { const snode_t Lc = load_node(nodes, fc + m - 1); last_end = Lc.s[0] + Lc.s[1]; }  // the non-LEAF children come first
-            if (STATS && lane == 0 && m) ib += 32;
-            for (uint32_t i = lane; i < m; i += 64) { cx.ccnt[i] = 0; cx.conly[i] = 0; cx.cpre[i] = nodes[fc + i].pre; if (STATS) ib += 4; }  // children tile [pre+1, last_end)
-            if (lane == 0) cx.cpre[m] = last_end;
-            wave_sync();
-            uint32_t u_lane = 0;
-            auto walk = [&](uint32_t v, uint32_t vh, uint32_t xx, uint32_t w) {
-                uint32_t nin = 0, which = 0;
-                while (v < last_end) {  // v lies under exactly one non-LEAF child: the last one that starts at or before it
-                    uint32_t lo_ = 0, hi_ = m;
-                    while (hi_ - lo_ > 1) { const uint32_t mid = (lo_ + hi_) >> 1; if (cx.cpre[mid] <= v) lo_ = mid; else hi_ = mid; }
-                    const uint32_t c_end = cx.cpre[lo_ + 1];  // (back to back: the next child starts where this one ends)
-                    atomicAdd(&cx.ccnt[lo_], w);
-                    if (nin == 0) which = lo_;
-                    if (nin < 2) ++nin;
-                    if (vh < c_end) break;                                         // no tip beyond this child
-                    const uint2 t = ldx<uint2, ADDR32>(half, 2 * xx + 1);          // first tip beyond it, the split of the rest
-                    if (STATS) ib += 8;
-                    v = t.x; xx = t.y;
-                }
-                if (nin == 1) atomicAdd(&cx.conly[which], w);
-                u_lane += nin ? w : 0u;
-            };
-            walk(vlo, vhi, x, wt);
-#pragma unroll 1
-            for (uint32_t c = 1; c < n_chunks; ++c) { const uint4 g = cx.stage[c * 64 + lane]; walk(g.x, g.y, g.z, g.w); }
-            const uint32_t U = wave_sum(u_lane);
-            wave_sync();
             // (one, rest), place_sequence.rs:369-395, with |R_c| = |U| - |only_c| and |R_c \ K_c| = |U| - |K_c|
             uint32_t n_pass = 0, n_best = 0, best_row = 0;
             int32_t best_one = 0, best_rest = 0, best_diff = 0;
-            for (uint32_t base = 0; base < m; base += 64) {
-                const uint32_t ci = base + lane;
-                bool pass = false;
-                int32_t one = 0, rest = 0;
-                if (ci < m) {
-                    const uint32_t cn = cx.ccnt[ci], on = cx.conly[ci];
-                    if (cn) { one = (int32_t)(rm ? on : cn); rest = (int32_t)(rm ? U - cn : U - on); pass = one > rest; }
-                }
-                uint64_t pm = __ballot(pass);
-                while (pm) {  // at most one child can pass; kept general for fidelity with :519-599
-                    const int src = __ffsll((unsigned long long)pm) - 1;
-                    const int32_t o1 = __shfl(one, src), r1 = __shfl(rest, src);
-                    const int32_t diff = o1 - r1;
-                    if (n_pass == 0 || diff > best_diff) { best_diff = diff; n_best = 1; best_row = fc + base + src; best_one = o1; best_rest = r1; }
+            if (m <= 4) {
+                // ---- at most four non-LEAF children (nearly every polytomy of a support-collapsed tree): the children's
+                // boundaries are scalars (the node record + its `kids` record), the child under a tip is three compares,
+                // the per-child counters are packed per-lane registers reduced like the binary counters: no LDS, no
+                // atomics, no extra round trip for the children's records.  Cost per group = children it has tips under.
+                const uint32_t B0 = P.s[0] + 1, B1 = P.s[6], B2 = K.s[0], B3 = K.s[1], B4 = K.s[2];
+                const uint32_t last_end = m == 0 ? B0 : m == 1 ? B1 : m == 2 ? B2 : m == 3 ? B3 : B4;  // end of the last non-LEAF child
+                uint32_t cA = 0, cB = 0, oA = 0, oB = 0, u_lane = 0;  // |K_0| | |K_1| << 16, |K_2| | |K_3| << 16; likewise |only_c|; |U|
+                auto walk4 = [&](uint32_t v, uint32_t vh, uint32_t xx, uint32_t w) {
+                    uint32_t nin = 0, which = 0;
+                    while (v < last_end) {  // v lies under exactly one non-LEAF child
+                        const uint32_t c = (v >= B1 ? 1u : 0u) + (v >= B2 ? 1u : 0u) + (v >= B3 ? 1u : 0u);
+                        const uint32_t c_end = c == 0 ? B1 : c == 1 ? B2 : c == 2 ? B3 : B4;
+                        const uint32_t inc = w << (16 * (c & 1u));
+                        if (c < 2) cA += inc; else cB += inc;
+                        if (nin == 0) which = c;
+                        if (nin < 2) ++nin;
+                        if (vh < c_end) break;                                         // no tip beyond this child
+                        const uint2 t = ldx<uint2, ADDR32>(half, 2 * xx + 1);          // first tip beyond it, the split of the rest
+                        if (STATS) ib += 8;
+                        v = t.x; xx = t.y;
+                    }
+                    if (nin == 1) { const uint32_t inc = w << (16 * (which & 1u)); if (which < 2) oA += inc; else oB += inc; }
+                    u_lane += nin ? w : 0u;
+                };
+                walk4(vlo, vhi, x, wt);
+#pragma unroll 1
+                for (uint32_t c = 1; c < n_chunks; ++c) { const uint4 g = cx.stage[c * 64 + lane]; walk4(g.x, g.y, g.z, g.w); }
+                cA = wave_sum(cA); cB = wave_sum(cB); oA = wave_sum(oA); oB = wave_sum(oB);
+                const uint32_t U = wave_sum(u_lane);
+#pragma unroll
+                for (uint32_t ci = 0; ci < 4; ++ci) {
+                    if (ci >= m) break;
+                    const uint32_t cn = ((ci < 2 ? cA : cB) >> (16 * (ci & 1u))) & 0xFFFFu, on = ((ci < 2 ? oA : oB) >> (16 * (ci & 1u))) & 0xFFFFu;
+                    if (!cn) continue;  // K_c empty: not a candidate (:329)
+                    const int32_t one = (int32_t)(rm ? on : cn), rest = (int32_t)(rm ? U - cn : U - on);
+                    if (one <= rest) continue;  // :411-417
+                    const int32_t diff = one - rest;
+                    if (n_pass == 0 || diff > best_diff) { best_diff = diff; n_best = 1; best_row = fc + ci; best_one = one; best_rest = rest; }
                     else if (diff == best_diff) ++n_best;
                     ++n_pass;
-                    pm &= pm - 1;
                 }
+            } else {
+                // ---- any arity up to FAST_MAX_ARITY: children's intervals and per-child counters in LDS
+                uint32_t last_end = 0;
+                if (m) { const snode_t Lc = load_node(nodes, fc + m - 1); last_end = Lc.s[0] + Lc.s[1]; }  // the non-LEAF children come first
+                if (STATS && lane == 0 && m) ib += 32;
+                for (uint32_t i = lane; i < m; i += 64) { cx.ccnt[i] = 0; cx.conly[i] = 0; cx.cpre[i] = nodes[fc + i].pre; if (STATS) ib += 4; }  // children tile [pre+1, last_end)
+                if (lane == 0) cx.cpre[m] = last_end;
+                wave_sync();
+                uint32_t u_lane = 0;
+                auto walk = [&](uint32_t v, uint32_t vh, uint32_t xx, uint32_t w) {
+                    uint32_t nin = 0, which = 0;
+                    while (v < last_end) {  // v lies under exactly one non-LEAF child: the last one that starts at or before it
+                        uint32_t lo_ = 0, hi_ = m;
+                        while (hi_ - lo_ > 1) { const uint32_t mid = (lo_ + hi_) >> 1; if (cx.cpre[mid] <= v) lo_ = mid; else hi_ = mid; }
+                        const uint32_t c_end = cx.cpre[lo_ + 1];  // (back to back: the next child starts where this one ends)
+                        atomicAdd(&cx.ccnt[lo_], w);
+                        if (nin == 0) which = lo_;
+                        if (nin < 2) ++nin;
+                        if (vh < c_end) break;                                         // no tip beyond this child
+                        const uint2 t = ldx<uint2, ADDR32>(half, 2 * xx + 1);          // first tip beyond it, the split of the rest
+                        if (STATS) ib += 8;
+                        v = t.x; xx = t.y;
+                    }
+                    if (nin == 1) atomicAdd(&cx.conly[which], w);
+                    u_lane += nin ? w : 0u;
+                };
+                walk(vlo, vhi, x, wt);
+    #pragma unroll 1
+                for (uint32_t c = 1; c < n_chunks; ++c) { const uint4 g = cx.stage[c * 64 + lane]; walk(g.x, g.y, g.z, g.w); }
+                const uint32_t U = wave_sum(u_lane);
+                wave_sync();
+                for (uint32_t base = 0; base < m; base += 64) {
+                    const uint32_t ci = base + lane;
+                    bool pass = false;
+                    int32_t one = 0, rest = 0;
+                    if (ci < m) {
+                        const uint32_t cn = cx.ccnt[ci], on = cx.conly[ci];
+                        if (cn) { one = (int32_t)(rm ? on : cn); rest = (int32_t)(rm ? U - cn : U - on); pass = one > rest; }
+                    }
+                    uint64_t pm = __ballot(pass);
+                    while (pm) {  // at most one child can pass; kept general for fidelity with :519-599
+                        const int src = __ffsll((unsigned long long)pm) - 1;
+                        const int32_t o1 = __shfl(one, src), r1 = __shfl(rest, src);
+                        const int32_t diff = o1 - r1;
+                        if (n_pass == 0 || diff > best_diff) { best_diff = diff; n_best = 1; best_row = fc + base + src; best_one = o1; best_rest = r1; }
+                        else if (diff == best_diff) ++n_best;
+                        ++n_pass;
+                        pm &= pm - 1;
+                    }
+                }
+                wave_sync();
             }
-            wave_sync();
             const uint64_t pid = ((uint64_t)P.s[5] << 32) | P.s[4];
             if (n_pass == 0) {
                 if (iteration == 1) write_record(out, r, CLS_UNCLASSIFIABLE_LEVEL1, 0, 0, 1, 0);
@@ -1234,6 +1292,7 @@ __device__ __forceinline__ void descend_groups(const DbDev& db, const PlaceParam
             }
             if (n_pass > 1 && n_best != 1) { write_record(out, r, CLS_INCONCLUSIVE, (int32_t)n_pass, 0, (uint32_t)iteration, pid); return; }
             P = load_node(nodes, best_row);
+            K = load_kids(db.kids, best_row);
             if (STATS && lane == 0) ib += 32;
             if (P.s[3] == 0) {
                 write_record(out, r, CLS_IDENTITY_FOUND, best_one, best_rest, (uint32_t)iteration, ((uint64_t)P.s[5] << 32) | P.s[4]);
@@ -1306,6 +1365,7 @@ __device__ __forceinline__ void descend_groups(const DbDev& db, const PlaceParam
         // ... and the chosen child's node record is requested before the narrowing, not waited for until after it
         // (the narrowing of a read's last level is wasted work: one level in sixteen)
         P = load_node(db.nodes, fc + (right ? 1u : 0u));
+        if (POLY) K = load_kids(db.kids, fc + (right ? 1u : 0u));
         __builtin_amdgcn_sched_barrier(0);  // keep the request up here (the scheduler sinks scalar loads to their first use)
         if (STATS && lane == 0) ib += 32;
 #if !CLS_DESCENT_SPEC
