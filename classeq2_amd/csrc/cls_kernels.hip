@@ -1198,32 +1198,22 @@ __device__ __forceinline__ void descend_groups(const DbDev& db, const PlaceParam
                 const uint32_t B0 = P.s[0] + 1, B1 = P.s[6], B2 = K.s[0], B3 = K.s[1], B4 = K.s[2];
                 const uint32_t last_end = m == 0 ? B0 : m == 1 ? B1 : m == 2 ? B2 : m == 3 ? B3 : B4;  // end of the last non-LEAF child
                 uint32_t cA = 0, cB = 0, oA = 0, oB = 0, u_lane = 0;  // |K_0| | |K_1| << 16, |K_2| | |K_3| << 16; likewise |only_c|; |U|
-                auto child_of = [&](uint32_t v) { return (v >= B1 ? 1u : 0u) + (v >= B2 ? 1u : 0u) + (v >= B3 ? 1u : 0u); };
-                auto add16 = [&](uint32_t& a, uint32_t& b, uint32_t c, uint32_t w) { const uint32_t inc = w << (16 * (c & 1u)); if (c < 2) a += inc; else b += inc; };
                 auto walk4 = [&](uint32_t v, uint32_t vh, uint32_t xx, uint32_t w) {
-                    if (v >= last_end) return;  // no tip under a non-LEAF child (or the inactive entry {MAX, 0})
-                    const uint32_t which = child_of(v);  // the child under the first tip ...
-                    add16(cA, cB, which, w);
-                    uint32_t nin = 1, c = which;
-                    // ... and the one under the last tip are known without a read; only a group that spans three or more
-                    // children (or reaches into the LEAF children) has to walk its chain for the ones in between
-                    const uint32_t c_hi = vh < last_end ? child_of(vh) : 0xFFu;
-                    if (c_hi == which + 1) { add16(cA, cB, c_hi, w); nin = 2; }
-                    else if (c_hi != which) {
-                        for (;;) {
-                            const uint32_t c_end = c == 0 ? B1 : c == 1 ? B2 : c == 2 ? B3 : B4;
-                            if (vh < c_end) break;                                         // no tip beyond this child
-                            const uint2 t = ldx<uint2, ADDR32>(half, 2 * xx + 1);          // first tip beyond it, the split of the rest
-                            if (STATS) ib += 8;
-                            v = t.x; xx = t.y;
-                            if (v >= last_end) break;
-                            c = child_of(v);
-                            add16(cA, cB, c, w);
-                            nin = 2;
-                        }
+                    uint32_t nin = 0, which = 0;
+                    while (v < last_end) {  // v lies under exactly one non-LEAF child
+                        const uint32_t c = (v >= B1 ? 1u : 0u) + (v >= B2 ? 1u : 0u) + (v >= B3 ? 1u : 0u);
+                        const uint32_t c_end = c == 0 ? B1 : c == 1 ? B2 : c == 2 ? B3 : B4;
+                        const uint32_t inc = w << (16 * (c & 1u));
+                        if (c < 2) cA += inc; else cB += inc;
+                        if (nin == 0) which = c;
+                        if (nin < 2) ++nin;
+                        if (vh < c_end) break;                                         // no tip beyond this child
+                        const uint2 t = ldx<uint2, ADDR32>(half, 2 * xx + 1);          // first tip beyond it, the split of the rest
+                        if (STATS) ib += 8;
+                        v = t.x; xx = t.y;
                     }
-                    if (nin == 1) add16(oA, oB, which, w);
-                    u_lane += w;
+                    if (nin == 1) { const uint32_t inc = w << (16 * (which & 1u)); if (which < 2) oA += inc; else oB += inc; }
+                    u_lane += nin ? w : 0u;
                 };
                 walk4(vlo, vhi, x, wt);
 #pragma unroll 1
