@@ -181,3 +181,18 @@ def test_encoded_index_answers_membership_like_the_node_sets(case):
     out = np.zeros(3, dtype=np.uint8)
     d = flats[0].desc()
     assert L.cls_db_debug_members(C.byref(d), absent.ctypes.data, ids[:3].copy().ctypes.data, 3, out.ctypes.data) == 0 and (out == 2).all()
+
+
+def test_tuning_knobs_are_explicit():
+    """Experiment knobs go through cls_set_tuning (the library reads no environment variable on its own): known names
+    are accepted, unknown ones refused; cls_tuning_from_env is an explicit call."""
+    engine.set_tuning("order_mode", 0)
+    engine.set_tuning("no_fat_direct", 0)
+    with pytest.raises(engine.ClsError, match="unknown knob"):
+        engine.set_tuning("no_such_knob", 1)
+    os.environ["CLS_ORDER_BLOCK_SHIFT"] = "2"  # the default value: harmless
+    engine.tuning_from_env()
+    del os.environ["CLS_ORDER_BLOCK_SHIFT"]
+    import subprocess
+    src = open(os.path.join(os.path.dirname(engine.LIB_PATH), "cls_kernels.hip")).read() + open(os.path.join(os.path.dirname(engine.LIB_PATH), "cls_db.cpp")).read()
+    assert "getenv" not in src  # only cls_tuning_from_env (cls_api.cpp) touches the environment
