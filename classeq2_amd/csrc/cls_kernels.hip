@@ -2282,7 +2282,7 @@ __device__ __forceinline__ snode_pair_t load_node_pair(const DNode* nodes, uint3
 }
 
 template <int THREADS, bool CANON, bool STATS, bool ADDR32>
-__global__ __launch_bounds__(THREADS, 4) void place_tile_kernel(DbDev db, PlaceParams prm, const uint8_t* __restrict__ bases,
+__global__ __launch_bounds__(THREADS) void place_tile_kernel(DbDev db, PlaceParams prm, const uint8_t* __restrict__ bases,
                                                              const uint64_t* __restrict__ offsets, const uint32_t* __restrict__ list,
                                                              const uint32_t* __restrict__ list_len, cls_placement* __restrict__ out,
                                                              cls_query_stats* __restrict__ stats, uint32_t max_lookups, uint32_t max_bases,
@@ -2511,44 +2511,38 @@ __global__ __launch_bounds__(THREADS, 4) void place_tile_kernel(DbDev db, PlaceP
             // and count it against the split of that clade's children
             const uint32_t a1n = Pn.s[6];
             c_ab = 0; c_both = 0;
-            // (every thread owns at most TILE_OWN entries: all their LDS reads first, then all their split reads in
-            // flight together, then the arithmetic -- ONE global round trip per level, not one per batch of entries)
-            constexpr int TILE_OWN = 8;  // (128 registers per lane: 16 waves per CU; a second trip beyond 8 x THREADS entries)
-            for (uint32_t j0 = tid; j0 < n_groups; j0 += TILE_OWN * THREADS) {
-                uint64_t h[TILE_OWN];
-                uint32_t xv[TILE_OWN];
-                uint2 t[TILE_OWN];
-                uint32_t strm = 0;
+            for (uint32_t j0 = tid; j0 < n_groups; j0 += 4 * THREADS) {
+                uint64_t h[4];
+                uint32_t xv[4];
+                uint2 t[4];
+                bool str[4];
 #pragma unroll
-                for (int i = 0; i < TILE_OWN; ++i) {
+                for (int i = 0; i < 4; ++i) {
                     const uint32_t j = j0 + i * THREADS;
                     h[i] = j < n_groups ? hot[j] : (uint64_t)TILE_TIP_MASK;  // beyond the end: the inactive entry {MAX, 0}, weight 0
                 }
 #pragma unroll
-                for (int i = 0; i < TILE_OWN; ++i) {
+                for (int i = 0; i < 4; ++i) {
                     const uint32_t j = j0 + i * THREADS;
                     const uint32_t lo_ = (uint32_t)h[i] & TILE_TIP_MASK, hi_ = (uint32_t)(h[i] >> TILE_TIP_BITS) & TILE_TIP_MASK;
-                    const bool str = lo_ < a1 && hi_ >= a1 && (right || lo_ != a0);
-                    strm |= (str ? 1u : 0u) << i;
-                    xv[i] = str ? xs[j] : 0u;
+                    str[i] = lo_ < a1 && hi_ >= a1 && (right || lo_ != a0);
+                    xv[i] = str[i] ? xs[j] : 0u;
                 }
 #pragma unroll
-                for (int i = 0; i < TILE_OWN; ++i) {
-                    const bool str = (strm >> i) & 1u;
-                    t[i] = ldx<uint2, ADDR32>(half, str ? 2 * xv[i] + (right ? 1u : 0u) : 0u);  // (record 0: the dummy)
-                    if (STATS && str) ib += 8;
+                for (int i = 0; i < 4; ++i) {
+                    t[i] = ldx<uint2, ADDR32>(half, str[i] ? 2 * xv[i] + (right ? 1u : 0u) : 0u);  // (record 0: the dummy)
+                    if (STATS && str[i]) ib += 8;
                 }
 #pragma unroll
-                for (int i = 0; i < TILE_OWN; ++i) {
+                for (int i = 0; i < 4; ++i) {
                     const uint32_t j = j0 + i * THREADS;
-                    const bool str = (strm >> i) & 1u;
                     uint32_t lo_ = (uint32_t)h[i] & TILE_TIP_MASK, hi_ = (uint32_t)(h[i] >> TILE_TIP_BITS) & TILE_TIP_MASK;
                     const uint32_t w = (uint32_t)(h[i] >> (2 * TILE_TIP_BITS));
-                    if (str) { if (!right) hi_ = t[i].x; else lo_ = t[i].x; xs[j] = t[i].y; }
+                    if (str[i]) { if (!right) hi_ = t[i].x; else lo_ = t[i].x; xs[j] = t[i].y; }
                     const bool gone = !right ? (lo_ >= a1 || lo_ == a0)    // no tip strictly below the first child
                                              : (hi_ < a1 || lo_ == a1);    // nothing in the second child, or it is the tip itself
                     if (gone) { lo_ = TILE_TIP_MASK; hi_ = 0; }
-                    if ((str || gone) && j < n_groups) hot[j] = (uint64_t)lo_ | ((uint64_t)hi_ << TILE_TIP_BITS) | ((uint64_t)w << (2 * TILE_TIP_BITS));
+                    if ((str[i] || gone) && j < n_groups) hot[j] = (uint64_t)lo_ | ((uint64_t)hi_ << TILE_TIP_BITS) | ((uint64_t)w << (2 * TILE_TIP_BITS));
                     const bool ina = lo_ < a1n, inb = hi_ >= a1n;
                     c_ab += (ina ? w : 0u) | ((inb ? w : 0u) << 16);
                     c_both += (ina && inb) ? w : 0u;
