@@ -40,7 +40,10 @@ constexpr int WAVES_PER_BLOCK = 4;
 #define FAST_MIN_WAVES 5  // 96 VGPRs: 5 workgroups per CU measured best on C3 (4: 9.2 ms, 5: 8.5, 6: 9.1 with more spills)
 #endif
 #ifndef CLS_DESCENT_SPEC
-#define CLS_DESCENT_SPEC 0  // 1: a level's split record (chunk 0) and node record are requested off its dependent chain (measured: 7.21 ms against 7.19 ms on C3 at the same occupancy, and twice the split bytes requested: off)
+#define CLS_DESCENT_SPEC 0  // (measured, C3: 0 = 6.79 ms; 1 = 6.87; 2 = 7.18: the kernel is bound by instructions issued, not by these waits)
+                            // taking a level's memory round trips off its dependent chain: 1 = the split record of chunk 0 is requested before
+                            // the counting (alone: 7.21 against 7.19 ms on C3, the node record still waited for); 2 = and both children's
+                            // node records arrive a level ahead (one 64-byte scalar load), so a decision needs no read at all
 #endif
 #ifndef CLS_NARROW_CANON_BITS
 #define CLS_NARROW_CANON_BITS 9  // LDS tables of the narrow class on a strand-symmetric index (at most 160 lookups per read): 2^bits entries
@@ -961,6 +964,17 @@ __device__ __forceinline__ snode_t load_node(const DNode* nodes, uint32_t row) {
     return r;
 }
 
+// both children of a binary clade (consecutive rows): one 64-byte scalar load
+struct snode_pair_t { uint32_t s[16]; };
+__device__ __forceinline__ snode_pair_t load_node_pair(const DNode* nodes, uint32_t row) {
+    typedef __attribute__((address_space(4))) const uint32_t as4_u32;
+    as4_u32* p = (as4_u32*)(uintptr_t)(nodes + __builtin_amdgcn_readfirstlane(row));
+    snode_pair_t r;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) r.s[i] = p[i];
+    return r;
+}
+
 // Where the third, fourth and fifth child of a clade start (DbDev.kids): 16 bytes through the scalar unit.
 struct skids_t { uint32_t s[4]; };
 __device__ __forceinline__ skids_t load_kids(const uint32_t* kids, uint32_t row) {
@@ -1153,6 +1167,10 @@ __device__ __forceinline__ bool hash_front(const DbDev& db, const FastCtx& cx, c
     return true;
 }
 
+// Inactive group of the descent: {GRP_INACTIVE, 0}.  Below 2^31, so that `a < b` can be taken as the sign of a - b.
+constexpr uint32_t GRP_INACTIVE = 0x7FFFFFFFu;
+__device__ __forceinline__ uint32_t mask_lt(uint32_t a, uint32_t b) { return (uint32_t)((int32_t)(a - b) >> 31); }  // ~0 if a < b (both < 2^31)
+
 // The descent (C) on the read's tip-set groups, staged in cx.stage[0 .. n_sets).  PACK10: at most 1023 k-mers per read,
 // three 10-bit counters share a word.  (A two-kernel form -- front writes the groups, this runs as its own kernel at 39
 // VGPRs and 8 waves per SIMD -- was measured: 7.4 ms against 6.85 ms fused on C3; more reads in flight do not pay for
@@ -1163,11 +1181,11 @@ __device__ __forceinline__ void descend_groups(const DbDev& db, const PlaceParam
                                                uint32_t r, cls_placement* __restrict__ out, uint32_t& ib) {
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t n_chunks = uniform((n_sets + 63) >> 6);  // wave-uniform; >= 1 here (some k-mer has the root and tips... or none: then 0)
-    if (n_sets + lane < 64 * n_chunks) cx.stage[n_sets + lane] = uint4{0xFFFFFFFFu, 0u, 0u, 0u};  // pad the last chunk with inactive entries
+    if (n_sets + lane < 64 * n_chunks) cx.stage[n_sets + lane] = uint4{GRP_INACTIVE, 0u, 0u, 0u};  // pad the last chunk with inactive entries
     wave_sync();
     uint32_t vlo, vhi, x, wt;  // chunk 0
     {
-        const uint4 g = n_chunks ? cx.stage[lane] : uint4{0xFFFFFFFFu, 0u, 0u, 0u};
+        const uint4 g = n_chunks ? cx.stage[lane] : uint4{GRP_INACTIVE, 0u, 0u, 0u};
         vlo = g.x; vhi = g.y; x = g.z; wt = g.w;
     }
     // ---- C. descent -----------------------------------------------------------------------------------
@@ -1175,6 +1193,10 @@ __device__ __forceinline__ void descend_groups(const DbDev& db, const PlaceParam
     const bool rm = prm.remove_intersection != 0;
     skids_t K{};  // polytomy trees: where the current clade's third .. fifth child start, fetched with its node record
     if (POLY) K = load_kids(db.kids, 0);
+#if CLS_DESCENT_SPEC >= 2
+    snode_pair_t C{};  // the two children of the current clade when it has exactly two: requested as soon as the clade is known
+    if ((P.s[7] >> 8) == 2) { C = load_node_pair(db.nodes, P.s[2]); if (STATS && lane == 0) ib += 64; }
+#endif
     int32_t iteration = 0;
     for (;;) {
         ++iteration;
@@ -1293,6 +1315,9 @@ __device__ __forceinline__ void descend_groups(const DbDev& db, const PlaceParam
             if (n_pass > 1 && n_best != 1) { write_record(out, r, CLS_INCONCLUSIVE, (int32_t)n_pass, 0, (uint32_t)iteration, pid); return; }
             P = load_node(nodes, best_row);
             K = load_kids(db.kids, best_row);
+#if CLS_DESCENT_SPEC >= 2
+            if ((P.s[7] >> 8) == 2) { C = load_node_pair(nodes, P.s[2]); if (STATS && lane == 0) ib += 64; }
+#endif
             if (STATS && lane == 0) ib += 32;
             if (P.s[3] == 0) {
                 write_record(out, r, CLS_IDENTITY_FOUND, best_one, best_rest, (uint32_t)iteration, ((uint64_t)P.s[5] << 32) | P.s[4]);
@@ -1310,7 +1335,7 @@ __device__ __forceinline__ void descend_groups(const DbDev& db, const PlaceParam
                 }
                 if (!dead && v < c_end && v != c0) {  // a tip strictly below the chosen clade
                     if (vh >= c_end) { const uint2 t = ldx<uint2, ADDR32>(half, 2 * xx); vh = t.x; xx = t.y; if (STATS) ib += 8; }
-                } else { v = 0xFFFFFFFFu; vh = 0; }
+                } else { v = GRP_INACTIVE; vh = 0; }
             };
             enter(vlo, vhi, x);
 #pragma unroll 1
@@ -1325,16 +1350,19 @@ __device__ __forceinline__ void descend_groups(const DbDev& db, const PlaceParam
         // The level's two memory round trips are taken off its dependent chain (waves spent two thirds of their time
         // parked on them): a group of chunk 0 that has tips on both sides of a1 will need one half of its split record
         // whichever child wins, so the whole 16-byte record is requested NOW, before the counting and the reduction ...
-#if CLS_DESCENT_SPEC
+#if CLS_DESCENT_SPEC >= 1
         const bool str_any0 = vlo < a1 && vhi >= a1;
         const uint4 rec0 = ldx<uint4, ADDR32>(reinterpret_cast<const uint4*>(half), str_any0 ? x : 0u);  // {tip_prev, L, tip, R}
         if (STATS && str_any0) ib += 16;
 #endif
         uint32_t c3 = 0, c3b = 0;  // per lane: k-mers in a | in b << 10 | in both << 20
+        // Lane predicates are kept as 0 / ~0 integer masks made by arithmetic (every value is below 2^31, an inactive group
+        // is {GRP_INACTIVE, 0}): `a && b` between two compare results costs an instruction on the ONE scalar unit of the
+        // CU (s_and_b64 on the lane masks), and the level loop was issuing more scalar than vector instructions.
         auto count = [&](uint32_t lo_, uint32_t hi_, uint32_t w) {
-            const uint32_t ina = lo_ < a1 ? w : 0u;    // lo >= a0 for an active set, MAX for an inactive one
-            const uint32_t inb = hi_ >= a1 ? w : 0u;   // hi < end of the parent for an active one, 0 for an inactive one
-            const uint32_t bo = (lo_ < a1 && hi_ >= a1) ? w : 0u;
+            const uint32_t ina = w & mask_lt(lo_, a1);    // lo >= a0 for an active group
+            const uint32_t inb = w & ~mask_lt(hi_, a1);   // hi < end of the parent for an active one, 0 for an inactive one
+            const uint32_t bo = ina & inb;                // (both are 0 or w)
             if (PACK10) c3 += ina | (inb << 10) | (bo << 20);
             else { c3 += ina | (inb << 16); c3b += bo; }
         };
@@ -1364,10 +1392,18 @@ __device__ __forceinline__ void descend_groups(const DbDev& db, const PlaceParam
         const bool right = only_b > only_a;
         // ... and the chosen child's node record is requested before the narrowing, not waited for until after it
         // (the narrowing of a read's last level is wasted work: one level in sixteen)
+#if CLS_DESCENT_SPEC >= 2
+#pragma unroll
+        for (int i = 0; i < 8; ++i) P.s[i] = right ? C.s[8 + i] : C.s[i];  // already here: no read on the way to the next level
+        if ((P.s[7] >> 8) == 2) { C = load_node_pair(db.nodes, P.s[2]); if (STATS && lane == 0) ib += 64; }
+        if (POLY) K = load_kids(db.kids, fc + (right ? 1u : 0u));
+        __builtin_amdgcn_sched_barrier(0);  // keep the requests up here (the scheduler sinks scalar loads to their first use)
+#else
         P = load_node(db.nodes, fc + (right ? 1u : 0u));
         if (POLY) K = load_kids(db.kids, fc + (right ? 1u : 0u));
         __builtin_amdgcn_sched_barrier(0);  // keep the request up here (the scheduler sinks scalar loads to their first use)
         if (STATS && lane == 0) ib += 32;
+#endif
 #if !CLS_DESCENT_SPEC
         if (P.s[3] == 0) {  // no non-LEAF child below the chosen clade (update_introspection_node.rs:45-85)
             const uint32_t cn = right ? cnt_b : cnt_a, on = right ? only_b : only_a;
@@ -1381,28 +1417,37 @@ __device__ __forceinline__ void descend_groups(const DbDev& db, const PlaceParam
             if (!right) {
                 const bool gone = vlo >= a1 || vlo == a0;  // no tip strictly below the first child
                 if (str) { vhi = rec0.x; x = rec0.y; }
-                if (gone) { vlo = 0xFFFFFFFFu; vhi = 0; }
+                if (gone) { vlo = GRP_INACTIVE; vhi = 0; }
             } else {
                 if (str) { vlo = rec0.z; x = rec0.w; }
                 const bool gone = vhi < a1 || vlo == a1;  // nothing in the second child, or it is the tip itself
-                if (gone) { vlo = 0xFFFFFFFFu; vhi = 0; }
+                if (gone) { vlo = GRP_INACTIVE; vhi = 0; }
             }
         }
 #endif
         // narrow: a set with tips on both sides of a1 reads 8 bytes of its split node (the half for the side
         // taken); everything else is arithmetic on (lo, hi).  Inactive afterwards = {MAX, 0}.
         auto narrow = [&](uint32_t& lo_, uint32_t& hi_, uint32_t& x_) {
-            const bool str = lo_ < a1 && hi_ >= a1 && (right || lo_ != a0);
-            const uint2 t = ldx<uint2, ADDR32>(half, str ? 2 * x_ + (right ? 1u : 0u) : 0u);
-            if (STATS && str) ib += 8;
+            const uint32_t lt = mask_lt(lo_, a1), ge = ~mask_lt(hi_, a1);  // a tip below a1 / a tip at or beyond a1
             if (!right) {
-                const bool gone = lo_ >= a1 || lo_ == a0;  // no tip strictly below the first child
-                if (str) { hi_ = t.x; x_ = t.y; }
-                if (gone) { lo_ = 0xFFFFFFFFu; hi_ = 0; }
+                const uint32_t ne0 = lo_ != a0 ? ~0u : 0u;
+                const uint32_t strm = lt & ge & ne0;                        // tips on both sides, and one strictly below the first child
+                const uint2 t = ldx<uint2, ADDR32>(half, (2 * x_) & strm);  // (record 0: the dummy)
+                if (STATS) ib += strm & 8u;
+                hi_ = (t.x & strm) | (hi_ & ~strm);
+                x_ = (t.y & strm) | (x_ & ~strm);
+                const uint32_t keep = lt & ne0;                             // a tip strictly below the first child
+                lo_ = (lo_ & keep) | (GRP_INACTIVE & ~keep);
+                hi_ &= keep;
             } else {
-                if (str) { lo_ = t.x; x_ = t.y; }
-                const bool gone = hi_ < a1 || lo_ == a1;  // nothing in the second child, or it is the tip itself
-                if (gone) { lo_ = 0xFFFFFFFFu; hi_ = 0; }
+                const uint32_t strm = lt & ge;
+                const uint2 t = ldx<uint2, ADDR32>(half, (2 * x_ + 1u) & strm);
+                if (STATS) ib += strm & 8u;
+                lo_ = (t.x & strm) | (lo_ & ~strm);
+                x_ = (t.y & strm) | (x_ & ~strm);
+                const uint32_t keep = ge & (lo_ != a1 ? ~0u : 0u);          // something in the second child, and not just the clade itself
+                lo_ = (lo_ & keep) | (GRP_INACTIVE & ~keep);
+                hi_ &= keep;
             }
         };
 #if !CLS_DESCENT_SPEC
@@ -2268,17 +2313,6 @@ __host__ __device__ inline uint32_t tile_packed_words(uint32_t max_bases) { retu
 // dynamic LDS of the tile kernel for reads of up to `max_lookups` table lookups and `max_bases` bases
 __host__ __device__ inline size_t tile_smem(uint32_t max_lookups, uint32_t max_bases) {
     return 4ull * tile_packed_words(max_bases) + 4ull * TILE_SET_ENTRIES + 8ull * max_lookups + 4ull * max_lookups + 16;
-}
-
-// both children of a binary clade (consecutive rows): one 64-byte scalar load
-struct snode_pair_t { uint32_t s[16]; };
-__device__ __forceinline__ snode_pair_t load_node_pair(const DNode* nodes, uint32_t row) {
-    typedef __attribute__((address_space(4))) const uint32_t as4_u32;
-    as4_u32* p = (as4_u32*)(uintptr_t)(nodes + __builtin_amdgcn_readfirstlane(row));
-    snode_pair_t r;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) r.s[i] = p[i];
-    return r;
 }
 
 template <int THREADS, bool CANON, bool STATS, bool ADDR32>
