@@ -1183,11 +1183,16 @@ __device__ __forceinline__ void descend_groups(const DbDev& db, const PlaceParam
     const uint32_t n_chunks = uniform((n_sets + 63) >> 6);  // wave-uniform; >= 1 here (some k-mer has the root and tips... or none: then 0)
     if (n_sets + lane < 64 * n_chunks) cx.stage[n_sets + lane] = uint4{GRP_INACTIVE, 0u, 0u, 0u};  // pad the last chunk with inactive entries
     wave_sync();
-    uint32_t vlo, vhi, x, wt;  // chunk 0
+    uint32_t vlo, vhi, x, wt;      // chunk 0 and ...
+    uint32_t vlo2, vhi2, x2, wt2;  // ... chunk 1 live in registers (a 150 bp read has 70-140 groups): no LDS traffic, no loop for them
+    constexpr bool REG2 = !POLY;   // (the polytomy kernels have no registers to spare: they keep chunk 1 in LDS)
     {
         const uint4 g = n_chunks ? cx.stage[lane] : uint4{GRP_INACTIVE, 0u, 0u, 0u};
         vlo = g.x; vhi = g.y; x = g.z; wt = g.w;
+        const uint4 g2 = (REG2 && n_chunks > 1) ? cx.stage[64 + lane] : uint4{GRP_INACTIVE, 0u, 0u, 0u};
+        vlo2 = g2.x; vhi2 = g2.y; x2 = g2.z; wt2 = g2.w;
     }
+    constexpr uint32_t CL = REG2 ? 2u : 1u;  // first chunk that stays in LDS
     // ---- C. descent -----------------------------------------------------------------------------------
     const uint32_t* __restrict__ half = db.postings;  // record x = 8-byte halves 2x (left part), 2x+1 (right part)
     const bool rm = prm.remove_intersection != 0;
@@ -1238,8 +1243,9 @@ __device__ __forceinline__ void descend_groups(const DbDev& db, const PlaceParam
                     u_lane += nin ? w : 0u;
                 };
                 walk4(vlo, vhi, x, wt);
+                if (REG2) walk4(vlo2, vhi2, x2, wt2);
 #pragma unroll 1
-                for (uint32_t c = 1; c < n_chunks; ++c) { const uint4 g = cx.stage[c * 64 + lane]; walk4(g.x, g.y, g.z, g.w); }
+                for (uint32_t c = CL; c < n_chunks; ++c) { const uint4 g = cx.stage[c * 64 + lane]; walk4(g.x, g.y, g.z, g.w); }
                 cA = wave_sum(cA); cB = wave_sum(cB); oA = wave_sum(oA); oB = wave_sum(oB);
                 const uint32_t U = wave_sum(u_lane);
 #pragma unroll
@@ -1281,8 +1287,9 @@ __device__ __forceinline__ void descend_groups(const DbDev& db, const PlaceParam
                     u_lane += nin ? w : 0u;
                 };
                 walk(vlo, vhi, x, wt);
-    #pragma unroll 1
-                for (uint32_t c = 1; c < n_chunks; ++c) { const uint4 g = cx.stage[c * 64 + lane]; walk(g.x, g.y, g.z, g.w); }
+                if (REG2) walk(vlo2, vhi2, x2, wt2);
+#pragma unroll 1
+                for (uint32_t c = CL; c < n_chunks; ++c) { const uint4 g = cx.stage[c * 64 + lane]; walk(g.x, g.y, g.z, g.w); }
                 const uint32_t U = wave_sum(u_lane);
                 wave_sync();
                 for (uint32_t base = 0; base < m; base += 64) {
@@ -1338,8 +1345,9 @@ __device__ __forceinline__ void descend_groups(const DbDev& db, const PlaceParam
                 } else { v = GRP_INACTIVE; vh = 0; }
             };
             enter(vlo, vhi, x);
+            if (REG2) enter(vlo2, vhi2, x2);
 #pragma unroll 1
-            for (uint32_t c = 1; c < n_chunks; ++c) {
+            for (uint32_t c = CL; c < n_chunks; ++c) {
                 uint4 g = cx.stage[c * 64 + lane];
                 enter(g.x, g.y, g.z);
                 cx.stage[c * 64 + lane] = g;
@@ -1367,8 +1375,9 @@ __device__ __forceinline__ void descend_groups(const DbDev& db, const PlaceParam
             else { c3 += ina | (inb << 16); c3b += bo; }
         };
         count(vlo, vhi, wt);
+        if (REG2) count(vlo2, vhi2, wt2);
 #pragma unroll 1
-        for (uint32_t c = 1; c < n_chunks; ++c) { const uint4 g = cx.stage[c * 64 + lane]; count(g.x, g.y, g.w); }
+        for (uint32_t c = CL; c < n_chunks; ++c) { const uint4 g = cx.stage[c * 64 + lane]; count(g.x, g.y, g.w); }
         uint32_t cnt_a, cnt_b, both;
         if (PACK10) {
             c3 = wave_sum(c3);
@@ -1453,8 +1462,9 @@ __device__ __forceinline__ void descend_groups(const DbDev& db, const PlaceParam
 #if !CLS_DESCENT_SPEC
         narrow(vlo, vhi, x);
 #endif
+        if (REG2) narrow(vlo2, vhi2, x2);
 #pragma unroll 1
-        for (uint32_t c = 1; c < n_chunks; ++c) {
+        for (uint32_t c = CL; c < n_chunks; ++c) {
             uint4 g = cx.stage[c * 64 + lane];
             narrow(g.x, g.y, g.z);
             cx.stage[c * 64 + lane] = g;
