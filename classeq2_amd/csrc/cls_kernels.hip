@@ -957,7 +957,9 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
 struct snode_t { uint32_t s[8]; };
 __device__ __forceinline__ snode_t load_node(const DNode* nodes, uint32_t row) {
     typedef __attribute__((address_space(4))) const uint32_t as4_u32;
-    as4_u32* p = (as4_u32*)(uintptr_t)(nodes + __builtin_amdgcn_readfirstlane(row));
+    typedef __attribute__((address_space(4))) const char as4_char;
+    // (a 32-bit byte offset off the table's base: the node table stays far below 4 GiB, and the scalar load takes base + offset)
+    as4_u32* p = (as4_u32*)((as4_char*)(uintptr_t)nodes + (uint32_t)(__builtin_amdgcn_readfirstlane(row) * (uint32_t)sizeof(DNode)));
     snode_t r;
 #pragma unroll
     for (int i = 0; i < 8; ++i) r.s[i] = p[i];
@@ -1018,6 +1020,22 @@ constexpr uint32_t FAST_MAX_ARITY = 256;  // non-LEAF children per clade the fas
 // FAT: the entry comes from the denormalised 16-byte table (`direct16`) together with its set record `rec` =
 // {root split, first tip | lg << 27, last tip | has_root << 31}: no second, dependent read.
 struct FatRec { uint32_t x, vlo_lg, vhi_root; };
+// The three per-read LDS tables back to empty, sixteen bytes per store (the tables start on 16-byte boundaries: they
+// double as the uint4 staging area); table_bits >= 2 whenever SET_BITS > 0.
+template <int SET_BITS>
+__device__ __forceinline__ void clear_tables(const FastCtx& cx, uint32_t table_bits, uint32_t lane) {
+    if constexpr (SET_BITS == 0) {
+        if (lane == 0) cx.set[0] = SET_EMPTY;
+    } else {
+        const uint4 ones = make_uint4(SET_EMPTY, SET_EMPTY, SET_EMPTY, SET_EMPTY), zero = make_uint4(0, 0, 0, 0);
+        uint4* const s4 = reinterpret_cast<uint4*>(cx.set);
+        uint4* const k4 = reinterpret_cast<uint4*>(cx.gkey);
+        uint4* const c4 = reinterpret_cast<uint4*>(cx.gcnt);
+#pragma unroll 1
+        for (uint32_t i = lane; i < (1u << table_bits) / 4; i += 64) { s4[i] = ones; k4[i] = ones; c4[i] = zero; }
+    }
+}
+
 template <int SLOTS, int SET_BITS, bool ADDR32, bool FAT = false>
 __device__ __forceinline__ bool fast_front(const DbDev& db, const FastCtx& cx, const uint8_t* __restrict__ bases, uint64_t b0,
                                            uint32_t L, uint32_t nf, uint32_t nk, uint32_t (&e)[SLOTS], uint32_t (&key)[SLOTS], uint32_t (&kw)[SLOTS],
@@ -1032,11 +1050,7 @@ __device__ __forceinline__ bool fast_front(const DbDev& db, const FastCtx& cx, c
         bad |= !(c == 'A' || c == 'C' || c == 'G' || c == 'T');
         cx.ascii[i] = c;
     }
-#pragma unroll 1
-    for (uint32_t i = lane; i < (1u << table_bits); i += 64) {  // (only the part of the tables this read will use)
-        cx.set[i] = SET_EMPTY;
-        if (SET_BITS) { cx.gkey[i] = SET_EMPTY; cx.gcnt[i] = 0; }
-    }
+    clear_tables<SET_BITS>(cx, table_bits, lane);  // (only the part of the tables this read will use)
     if (__ballot(bad)) return false;
     wave_sync();
     {
@@ -1109,11 +1123,7 @@ __device__ __forceinline__ bool hash_front(const DbDev& db, const FastCtx& cx, c
         cx.ascii[i] = c;
         cx.ascii[2 * L - 1 - i] = c ^ ((c & 2) ? 0x04 : 0x15);  // A<->T, C<->G
     }
-#pragma unroll 1
-    for (uint32_t i = lane; i < (1u << table_bits); i += 64) {
-        cx.set[i] = SET_EMPTY;
-        if (SET_BITS) { cx.gkey[i] = SET_EMPTY; cx.gcnt[i] = 0; }
-    }
+    clear_tables<SET_BITS>(cx, table_bits, lane);  // (only the part of the tables this read will use)
     if (__ballot(bad)) return false;
     wave_sync();
     const uint8_t* seq = cx.ascii;
@@ -1171,12 +1181,11 @@ __device__ __forceinline__ bool hash_front(const DbDev& db, const FastCtx& cx, c
 constexpr uint32_t GRP_INACTIVE = 0x7FFFFFFFu;
 __device__ __forceinline__ uint32_t mask_lt(uint32_t a, uint32_t b) { return (uint32_t)((int32_t)(a - b) >> 31); }  // ~0 if a < b (both < 2^31)
 
-// The descent (C) on the read's tip-set groups, staged in cx.stage[0 .. n_sets).  PACK10: at most 1023 k-mers per read,
-// three 10-bit counters share a word.  (A two-kernel form -- front writes the groups, this runs as its own kernel at 39
+// The descent (C) on the read's tip-set groups, staged in cx.stage[0 .. n_sets).  (A two-kernel form -- front writes the groups, this runs as its own kernel at 39
 // VGPRs and 8 waves per SIMD -- was measured: 7.4 ms against 6.85 ms fused on C3; more reads in flight do not pay for
 // writing and re-reading 1.6 GB of groups.)
 // STATS: `ib` accumulates (per lane) the index bytes the descent asks for: 32 per node record, 8 per split half.
-template <bool PACK10, bool ADDR32, bool POLY, bool STATS>
+template <bool ADDR32, bool POLY, bool STATS>
 __device__ __forceinline__ void descend_groups(const DbDev& db, const PlaceParams& prm, const FastCtx& cx, uint32_t n_sets, snode_t P,
                                                uint32_t r, cls_placement* __restrict__ out, uint32_t& ib) {
     const uint32_t lane = threadIdx.x & 63;
@@ -1193,6 +1202,10 @@ __device__ __forceinline__ void descend_groups(const DbDev& db, const PlaceParam
         vlo2 = g2.x; vhi2 = g2.y; x2 = g2.z; wt2 = g2.w;
     }
     constexpr uint32_t CL = REG2 ? 2u : 1u;  // first chunk that stays in LDS
+    uint32_t w_all = wt + wt2;  // sum of every group's weight, active or not: the constant of the level decision
+#pragma unroll 1
+    for (uint32_t c = CL; c < n_chunks; ++c) w_all += cx.stage[c * 64 + lane].w;
+    w_all = wave_sum(w_all);
     // ---- C. descent -----------------------------------------------------------------------------------
     const uint32_t* __restrict__ half = db.postings;  // record x = 8-byte halves 2x (left part), 2x+1 (right part)
     const bool rm = prm.remove_intersection != 0;
@@ -1363,42 +1376,49 @@ __device__ __forceinline__ void descend_groups(const DbDev& db, const PlaceParam
         const uint4 rec0 = ldx<uint4, ADDR32>(reinterpret_cast<const uint4*>(half), str_any0 ? x : 0u);  // {tip_prev, L, tip, R}
         if (STATS && str_any0) ib += 16;
 #endif
-        uint32_t c3 = 0, c3b = 0;  // per lane: k-mers in a | in b << 10 | in both << 20
-        // Lane predicates are kept as 0 / ~0 integer masks made by arithmetic (every value is below 2^31, an inactive group
-        // is {GRP_INACTIVE, 0}): `a && b` between two compare results costs an instruction on the ONE scalar unit of the
-        // CU (s_and_b64 on the lane masks), and the level loop was issuing more scalar than vector instructions.
-        auto count = [&](uint32_t lo_, uint32_t hi_, uint32_t w) {
-            const uint32_t ina = w & mask_lt(lo_, a1);    // lo >= a0 for an active group
-            const uint32_t inb = w & ~mask_lt(hi_, a1);   // hi < end of the parent for an active one, 0 for an inactive one
-            const uint32_t bo = ina & inb;                // (both are 0 or w)
-            if (PACK10) c3 += ina | (inb << 10) | (bo << 20);
-            else { c3 += ina | (inb << 16); c3b += bo; }
-        };
+        // (one, rest) of place_sequence.rs:369-395 with |R_c| = |U| - |only_c|, |R_c \ K_c| = |U| - |K_c|:
+        //   one_a - rest_a = |only_a| - |only_b| = |K_a| - |K_b| = -(one_b - rest_b)   for either remove_intersection,
+        // so exactly one child passes `one > rest` when the two differ and none when they tie: a level only
+        // needs the SIGN of |K_a| - |K_b|; the three counts themselves go into the record of the level the descent ends at
+        // and are taken there (`final_counts`).  With u(v) = 1 if v < a1 else 0 (the sign bit of v - a1: every value is
+        // below 2^31, an inactive group is {GRP_INACTIVE, 0}),
+        //   |K_a| - |K_b| = sum w [lo < a1] - sum w [hi >= a1] = sum w (u(lo) + u(hi)) - sum w      over ALL groups
+        // (an inactive group gives u(lo) + u(hi) = 0 + 1): six vector instructions a group, no lane predicates (`a && b`
+        // between two compare results is an s_and_b64 on the ONE scalar unit of the CU, and the level loop was issuing
+        // more scalar than vector instructions), one reduction.
+        // A LEAF child is not scored (:322-324): m < 2 takes the second child's count away (u(hi) = 1 for everyone), m = 0
+        // the first child's too (u(lo) = 0).
+        const uint32_t a1_lo = m == 0 ? 0u : a1, a1_hi = m < 2 ? GRP_INACTIVE : a1;
+        uint32_t acc = 0;
+        auto count = [&](uint32_t lo_, uint32_t hi_, uint32_t w) { acc += __umul24(w, ((lo_ - a1_lo) >> 31) + ((hi_ - a1_hi) >> 31)); };
         count(vlo, vhi, wt);
         if (REG2) count(vlo2, vhi2, wt2);
 #pragma unroll 1
         for (uint32_t c = CL; c < n_chunks; ++c) { const uint4 g = cx.stage[c * 64 + lane]; count(g.x, g.y, g.w); }
-        uint32_t cnt_a, cnt_b, both;
-        if (PACK10) {
-            c3 = wave_sum(c3);
-            cnt_a = c3 & 0x3FFu; cnt_b = (c3 >> 10) & 0x3FFu; both = c3 >> 20;
-        } else {
-            c3 = wave_sum(c3); c3b = wave_sum(c3b);
-            cnt_a = c3 & 0xFFFFu; cnt_b = c3 >> 16; both = c3b;
-        }
-        if (m == 0) cnt_a = 0;                 // no non-LEAF child: nothing is scored (:322-324)
-        if (m < 2) { cnt_b = 0; both = 0; }   // the second child is a LEAF
-        // (one, rest) of place_sequence.rs:369-395 with |R_c| = |U| - |only_c|, |R_c \ K_c| = |U| - |K_c|:
-        //   one_a - rest_a = |only_a| - |only_b| = -(one_b - rest_b)   for either remove_intersection,
-        // so exactly one child passes `one > rest` when the two differ and none when they tie.
-        const uint32_t only_a = cnt_a - both, only_b = cnt_b - both, U = cnt_a + cnt_b - both;
+        const int32_t diff_ab = (int32_t)(wave_sum(acc) - w_all);  // |K_a| - |K_b|
+        // |K_a|, |K_b|, |K_a ^ K_b| of this level: only the level the descent ends at asks
+        auto final_counts = [&](uint32_t& cnt_a, uint32_t& cnt_b, uint32_t& both) {
+            uint32_t ca = 0, cb = 0, bo = 0;
+            auto count3 = [&](uint32_t lo_, uint32_t hi_, uint32_t w) {
+                const uint32_t ina = w & mask_lt(lo_, a1);    // lo >= a0 for an active group
+                const uint32_t inb = w & ~mask_lt(hi_, a1);   // hi < end of the parent for an active one, 0 for an inactive one
+                ca += ina; cb += inb; bo += ina & inb;        // (both are 0 or w)
+            };
+            count3(vlo, vhi, wt);
+            if (REG2) count3(vlo2, vhi2, wt2);
+#pragma unroll 1
+            for (uint32_t c = CL; c < n_chunks; ++c) { const uint4 g = cx.stage[c * 64 + lane]; count3(g.x, g.y, g.w); }
+            cnt_a = m == 0 ? 0u : wave_sum(ca);
+            cnt_b = m < 2 ? 0u : wave_sum(cb);
+            both = m < 2 ? 0u : wave_sum(bo);
+        };
         const uint64_t pid = ((uint64_t)P.s[5] << 32) | P.s[4];
-        if (only_a == only_b) {
+        if (diff_ab == 0) {
             if (iteration == 1) write_record(out, r, CLS_UNCLASSIFIABLE_LEVEL1, 0, 0, 1, 0);
             else write_record(out, r, CLS_MAX_RESOLUTION, 0, 0, (uint32_t)iteration, pid);
             return;
         }
-        const bool right = only_b > only_a;
+        const bool right = diff_ab < 0;
         // ... and the chosen child's node record is requested before the narrowing, not waited for until after it
         // (the narrowing of a read's last level is wasted work: one level in sixteen)
 #if CLS_DESCENT_SPEC >= 2
@@ -1415,7 +1435,9 @@ __device__ __forceinline__ void descend_groups(const DbDev& db, const PlaceParam
 #endif
 #if !CLS_DESCENT_SPEC
         if (P.s[3] == 0) {  // no non-LEAF child below the chosen clade (update_introspection_node.rs:45-85)
-            const uint32_t cn = right ? cnt_b : cnt_a, on = right ? only_b : only_a;
+            uint32_t cnt_a, cnt_b, both;
+            final_counts(cnt_a, cnt_b, both);
+            const uint32_t cn = right ? cnt_b : cnt_a, on = cn - both, U = cnt_a + cnt_b - both;
             write_record(out, r, CLS_IDENTITY_FOUND, (int32_t)(rm ? on : cn), (int32_t)(rm ? U - cn : U - on), (uint32_t)iteration,
                          ((uint64_t)P.s[5] << 32) | P.s[4]);
             return;
@@ -1436,42 +1458,57 @@ __device__ __forceinline__ void descend_groups(const DbDev& db, const PlaceParam
 #endif
         // narrow: a set with tips on both sides of a1 reads 8 bytes of its split node (the half for the side
         // taken); everything else is arithmetic on (lo, hi).  Inactive afterwards = {MAX, 0}.
-        auto narrow = [&](uint32_t& lo_, uint32_t& hi_, uint32_t& x_) {
-            const uint32_t lt = mask_lt(lo_, a1), ge = ~mask_lt(hi_, a1);  // a tip below a1 / a tip at or beyond a1
-            if (!right) {
-                const uint32_t ne0 = lo_ != a0 ? ~0u : 0u;
-                const uint32_t strm = lt & ge & ne0;                        // tips on both sides, and one strictly below the first child
-                const uint2 t = ldx<uint2, ADDR32>(half, (2 * x_) & strm);  // (record 0: the dummy)
+        // Two steps, so that the reads of the two register chunks are in flight together (as one step per chunk the
+        // second read was only requested once the first had come back: two round trips a level instead of one), and one
+        // copy of the level per side (`right` is wave-uniform).
+        auto narrow_side = [&](auto side) {
+            constexpr bool RIGHT = decltype(side)::value;
+            auto request = [&](uint32_t lo_, uint32_t hi_, uint32_t x_, uint32_t& strm) -> uint2 {
+                const uint32_t lt = mask_lt(lo_, a1), ge = ~mask_lt(hi_, a1);  // a tip below a1 / a tip at or beyond a1
+                // tips on both sides (left: and one strictly below the first child)
+                strm = RIGHT ? (lt & ge) : (lt & ge & (lo_ != a0 ? ~0u : 0u));
                 if (STATS) ib += strm & 8u;
-                hi_ = (t.x & strm) | (hi_ & ~strm);
+                return ldx<uint2, ADDR32>(half, (2 * x_ + (RIGHT ? 1u : 0u)) & strm);  // (record 0: the dummy)
+            };
+            auto finish = [&](uint32_t& lo_, uint32_t& hi_, uint32_t& x_, uint32_t strm, uint2 t) {
                 x_ = (t.y & strm) | (x_ & ~strm);
-                const uint32_t keep = lt & ne0;                             // a tip strictly below the first child
+                uint32_t keep;
+                if (!RIGHT) {
+                    keep = mask_lt(lo_, a1) & (lo_ != a0 ? ~0u : 0u);           // a tip strictly below the first child
+                    hi_ = (t.x & strm) | (hi_ & ~strm);
+                } else {
+                    keep = ~mask_lt(hi_, a1);                                   // something in the second child ...
+                    lo_ = (t.x & strm) | (lo_ & ~strm);
+                    keep &= lo_ != a1 ? ~0u : 0u;                               // ... and not just the clade itself
+                }
                 lo_ = (lo_ & keep) | (GRP_INACTIVE & ~keep);
                 hi_ &= keep;
-            } else {
-                const uint32_t strm = lt & ge;
-                const uint2 t = ldx<uint2, ADDR32>(half, (2 * x_ + 1u) & strm);
-                if (STATS) ib += strm & 8u;
-                lo_ = (t.x & strm) | (lo_ & ~strm);
-                x_ = (t.y & strm) | (x_ & ~strm);
-                const uint32_t keep = ge & (lo_ != a1 ? ~0u : 0u);          // something in the second child, and not just the clade itself
-                lo_ = (lo_ & keep) | (GRP_INACTIVE & ~keep);
-                hi_ &= keep;
+            };
+            uint32_t s0 = 0, s1 = 0;
+            uint2 t0{}, t1{};
+#if !CLS_DESCENT_SPEC
+            t0 = request(vlo, vhi, x, s0);
+#endif
+            if (REG2) t1 = request(vlo2, vhi2, x2, s1);
+#if !CLS_DESCENT_SPEC
+            finish(vlo, vhi, x, s0, t0);
+#endif
+            if (REG2) finish(vlo2, vhi2, x2, s1, t1);
+#pragma unroll 1
+            for (uint32_t c = CL; c < n_chunks; ++c) {
+                uint4 g = cx.stage[c * 64 + lane];
+                uint32_t sm;
+                const uint2 t = request(g.x, g.y, g.z, sm);
+                finish(g.x, g.y, g.z, sm, t);
+                cx.stage[c * 64 + lane] = g;
             }
         };
-#if !CLS_DESCENT_SPEC
-        narrow(vlo, vhi, x);
-#endif
-        if (REG2) narrow(vlo2, vhi2, x2);
-#pragma unroll 1
-        for (uint32_t c = CL; c < n_chunks; ++c) {
-            uint4 g = cx.stage[c * 64 + lane];
-            narrow(g.x, g.y, g.z);
-            cx.stage[c * 64 + lane] = g;
-        }
+        if (right) narrow_side(std::true_type{}); else narrow_side(std::false_type{});
 #if CLS_DESCENT_SPEC
         if (P.s[3] == 0) {  // no non-LEAF child below the chosen clade (update_introspection_node.rs:45-85)
-            const uint32_t cn = right ? cnt_b : cnt_a, on = right ? only_b : only_a;
+            uint32_t cnt_a, cnt_b, both;
+            final_counts(cnt_a, cnt_b, both);
+            const uint32_t cn = right ? cnt_b : cnt_a, on = cn - both, U = cnt_a + cnt_b - both;
             write_record(out, r, CLS_IDENTITY_FOUND, (int32_t)(rm ? on : cn), (int32_t)(rm ? U - cn : U - on), (uint32_t)iteration,
                          ((uint64_t)P.s[5] << 32) | P.s[4]);
             return;
@@ -1642,7 +1679,7 @@ __device__ __forceinline__ void place_read_fast(const DbDev& db, const PlacePara
         const uint64_t exp_usize = (expected != expected) ? 0ull : (uint64_t)expected;
         if ((uint64_t)n_root < exp_usize) { put_index_bytes(); write_record(out, r, CLS_UNCLASSIFIABLE_COVERAGE, (int32_t)n_root, 0, 0, 0); return; }
     }
-    descend_groups<(SLOTS * 64 < 1024), ADDR32, POLY, STATS>(db, prm, cx, n_sets, P, r, out, ib);
+    descend_groups<ADDR32, POLY, STATS>(db, prm, cx, n_sets, P, r, out, ib);
     put_index_bytes();
 }
 
