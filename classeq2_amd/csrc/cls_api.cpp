@@ -90,6 +90,7 @@ struct cls_db {
     void* d_kids = nullptr;
     void* d_table = nullptr;
     void* d_postings = nullptr;
+    void* d_postings2 = nullptr;
     void* d_bucket_key = nullptr;
     void* d_direct = nullptr;
     void* d_direct16 = nullptr;
@@ -116,7 +117,7 @@ namespace {
 struct Knob { const char* name; int cls::Tuning::*field; };
 const Knob KNOBS[] = {
     {"no_fast", &cls::Tuning::no_fast}, {"no_order", &cls::Tuning::no_order}, {"force_list", &cls::Tuning::force_list},
-    {"no_fat_direct", &cls::Tuning::no_fat_direct}, {"no_tile", &cls::Tuning::no_tile}, {"tile_pass_codes", &cls::Tuning::tile_pass_codes}, {"blocks_per_cu", &cls::Tuning::blocks_per_cu}, {"key_blocks_per_cu", &cls::Tuning::key_blocks_per_cu},
+    {"no_mask_halves", &cls::Tuning::no_mask_halves}, {"no_fat_direct", &cls::Tuning::no_fat_direct}, {"no_tile", &cls::Tuning::no_tile}, {"tile_pass_codes", &cls::Tuning::tile_pass_codes}, {"blocks_per_cu", &cls::Tuning::blocks_per_cu}, {"key_blocks_per_cu", &cls::Tuning::key_blocks_per_cu},
     {"long_blocks_per_cu", &cls::Tuning::long_blocks_per_cu}, {"order_mode", &cls::Tuning::order_mode},
     {"order_windows", &cls::Tuning::order_windows}, {"order_both_strands", &cls::Tuning::order_both_strands},
     {"order_block_shift", &cls::Tuning::order_block_shift}, {"order_sample_shift", &cls::Tuning::order_sample_shift},
@@ -171,6 +172,7 @@ extern "C" void cls_db_destroy(cls_db* db) {
     if (db->d_kids) (void)hipFree(db->d_kids);
     if (db->d_table) (void)hipFree(db->d_table);
     if (db->d_postings) (void)hipFree(db->d_postings);
+    if (db->d_postings2) (void)hipFree(db->d_postings2);
     if (db->d_bucket_key) (void)hipFree(db->d_bucket_key);
     if (db->d_direct) (void)hipFree(db->d_direct);
     if (db->d_direct16) (void)hipFree(db->d_direct16);
@@ -209,6 +211,7 @@ extern "C" int cls_db_create(const cls_db_desc* d, int device, cls_db** out) {
             (e = up(&db->d_kids, E.kids.data(), E.kids.size() * 4)) != hipSuccess ||
             (e = up(&db->d_table, E.table.data(), E.table.size() * sizeof(cls::Slot))) != hipSuccess ||
             (e = up(&db->d_postings, E.postings.data(), E.postings.size() * 4)) != hipSuccess ||
+            (!E.postings2.empty() && (e = up(&db->d_postings2, E.postings2.data(), E.postings2.size() * 4)) != hipSuccess) ||
             (e = up(&db->d_bucket_key, E.bucket_key.data(), E.bucket_key.size() * 8)) != hipSuccess ||
             (!E.direct.empty() && (e = up(&db->d_direct, E.direct.data(), E.direct.size() * 4)) != hipSuccess) ||
             (!E.direct16.empty() && (e = up(&db->d_direct16, E.direct16.data(), E.direct16.size() * 4)) != hipSuccess) ||
@@ -221,6 +224,7 @@ extern "C" int cls_db_create(const cls_db_desc* d, int device, cls_db** out) {
         v.kids = (const uint32_t*)db->d_kids;
         v.table = (const cls::Slot*)db->d_table;
         v.postings = (const uint32_t*)db->d_postings;
+        v.postings2 = (const uint32_t*)db->d_postings2;
         v.bucket_key = (const uint64_t*)db->d_bucket_key;
         v.direct = (const uint32_t*)db->d_direct;
         v.direct16 = (const uint32_t*)db->d_direct16;
@@ -249,7 +253,7 @@ extern "C" int cls_db_create(const cls_db_desc* d, int device, cls_db** out) {
         i.n_closed_kmers = E.n_closed;
         i.table_slots = E.table.size();
         i.postings_words = E.postings.size();
-        i.hbm_bytes = E.nodes.size() * sizeof(cls::DNode) + E.table.size() * sizeof(cls::Slot) + E.postings.size() * 4 + E.bucket_key.size() * 8 + E.direct.size() * 4 + E.direct16.size() * 4 + E.sets.size() * sizeof(cls::SetRec);
+        i.hbm_bytes = E.nodes.size() * sizeof(cls::DNode) + E.table.size() * sizeof(cls::Slot) + (E.postings.size() + E.postings2.size()) * 4 + E.bucket_key.size() * 8 + E.direct.size() * 4 + E.direct16.size() * 4 + E.sets.size() * sizeof(cls::SetRec);
         i.max_read_kmers = (uint32_t)std::max<uint64_t>(cls::MAX_READ_KMERS, 2 * db->max_read_len);
         i.device = device;
         i.format = E.format;

@@ -394,6 +394,9 @@ int encode_db(const cls_db_desc* d, EncodedDb& E, std::string& err) {
         if (n_recs >= (1ULL << 32)) { err = "split trees exceed 2^32 records"; return CLS_E_BAD_DB; }
         HugeVec<uint32_t> recs((n_recs + 1) * 4, 0);
         recs[2] = 0xFFFFFFFFu;  // dummy {0, 0, first tip = MAX, 0}: decodes to "inactive"
+        const bool mask_halves = E.strictly_binary && !tuning().no_mask_halves;
+        HugeVec<uint32_t> recs2(mask_halves ? (n_recs + 1) * 4 : 0, 0);
+        if (mask_halves) recs2[2] = 0xFFFFFFFFu;
         E.sets.assign(NS + 1, SetRec{0u, 0xFFFFFFFFu, 0u, 0u});
         parallel_chunks(NS, nt, [&](unsigned, uint64_t lo, uint64_t hi) {
             std::vector<uint32_t> dd, stk, L, R, pos, span_lo, span_hi;
@@ -444,6 +447,21 @@ int encode_db(const cls_db_desc* d, EncodedDb& E, std::string& err) {
                     t[1] = L[i] ? at(L[i]) : 0;     // ... and its split
                     t[2] = tip[i];                  // descending into the RIGHT part: new first tip ...
                     t[3] = R[i] ? at(R[i]) : 0;     // ... and its split
+                    if (mask_halves) {  // the same record with narrow parts as bit masks (cls_device.h: MASK halves)
+                        uint32_t* u = &recs2[(size_t)at(i) * 4];
+                        u[0] = t[0]; u[1] = t[1]; u[2] = t[2]; u[3] = t[3];
+                        const uint32_t l0 = span_lo[i], r1 = span_hi[i];  // left part = tip[l0 .. i), right part = tip[i .. r1)
+                        if (tip[i - 1] - tip[l0] < MASK_HALF_SPAN) {
+                            uint32_t bits = 0;
+                            for (uint32_t j = l0; j < i; ++j) bits |= 1u << (tip[j] - tip[l0]);
+                            u[0] = tip[i - 1] | MASK_HALF; u[1] = bits;
+                        }
+                        if (tip[r1 - 1] - tip[i] < MASK_HALF_SPAN) {
+                            uint32_t bits = 0;
+                            for (uint32_t j = i; j < r1; ++j) bits |= 1u << (tip[j] - tip[i]);
+                            u[2] = tip[i] | MASK_HALF; u[3] = bits;
+                        }
+                    }
                 }
                 uint32_t lg = 0;
                 while (lg < 31 && (1u << lg) <= n) ++lg;  // bit length: small = specific to a small clade
@@ -455,6 +473,7 @@ int encode_db(const cls_db_desc* d, EncodedDb& E, std::string& err) {
             }
         });
         E.postings.swap(recs);
+        E.postings2.swap(recs2);
         lap("split trees");
     }
     // ---- 5. hash table (linear probing; parallel claims, then a duplicate check) -------------------------

@@ -39,12 +39,6 @@ constexpr int WAVES_PER_BLOCK = 4;
 #ifndef FAST_MIN_WAVES
 #define FAST_MIN_WAVES 5  // 96 VGPRs: 5 workgroups per CU measured best on C3 (4: 9.2 ms, 5: 8.5, 6: 9.1 with more spills)
 #endif
-#ifndef CLS_DESCENT_SPEC
-#define CLS_DESCENT_SPEC 0  // (measured, C3: 0 = 6.79 ms; 1 = 6.87; 2 = 7.18: the kernel is bound by instructions issued, not by these waits)
-                            // taking a level's memory round trips off its dependent chain: 1 = the split record of chunk 0 is requested before
-                            // the counting (alone: 7.21 against 7.19 ms on C3, the node record still waited for); 2 = and both children's
-                            // node records arrive a level ahead (one 64-byte scalar load), so a decision needs no read at all
-#endif
 #ifndef CLS_NARROW_CANON_BITS
 #define CLS_NARROW_CANON_BITS 9  // LDS tables of the narrow class on a strand-symmetric index (at most 160 lookups per read): 2^bits entries
 #endif
@@ -1180,12 +1174,21 @@ __device__ __forceinline__ bool hash_front(const DbDev& db, const FastCtx& cx, c
 // Inactive group of the descent: {GRP_INACTIVE, 0}.  Below 2^31, so that `a < b` can be taken as the sign of a - b.
 constexpr uint32_t GRP_INACTIVE = 0x7FFFFFFFu;
 __device__ __forceinline__ uint32_t mask_lt(uint32_t a, uint32_t b) { return (uint32_t)((int32_t)(a - b) >> 31); }  // ~0 if a < b (both < 2^31)
+// The same with the shift hidden from the optimiser: it otherwise recognises "sign-extended compare", turns every use of the
+// mask back into v_cmp + v_cndmask pairs and the AND / OR of two masks into s_and_b64 / s_or_b64 on the scalar unit.  Kept
+// opaque, `(a & m) | (b & ~m)` stays one v_bfi_b32 and three-input mask logic one v_bitop3_b32.
+__device__ __forceinline__ uint32_t sign_mask(uint32_t d) {
+    uint32_t m;
+    asm("v_ashrrev_i32_e32 %0, 31, %1" : "=v"(m) : "v"(d));
+    return m;
+}
+__device__ __forceinline__ uint32_t bfi(uint32_t m, uint32_t a, uint32_t b) { return (a & m) | (b & ~m); }  // m ? a : b, bit by bit
 
 // The descent (C) on the read's tip-set groups, staged in cx.stage[0 .. n_sets).  (A two-kernel form -- front writes the groups, this runs as its own kernel at 39
 // VGPRs and 8 waves per SIMD -- was measured: 7.4 ms against 6.85 ms fused on C3; more reads in flight do not pay for
 // writing and re-reading 1.6 GB of groups.)
 // STATS: `ib` accumulates (per lane) the index bytes the descent asks for: 32 per node record, 8 per split half.
-template <bool ADDR32, bool POLY, bool STATS>
+template <bool ADDR32, bool POLY, bool STATS, bool MANY>
 __device__ __forceinline__ void descend_groups(const DbDev& db, const PlaceParams& prm, const FastCtx& cx, uint32_t n_sets, snode_t P,
                                                uint32_t r, cls_placement* __restrict__ out, uint32_t& ib) {
     const uint32_t lane = threadIdx.x & 63;
@@ -1202,19 +1205,22 @@ __device__ __forceinline__ void descend_groups(const DbDev& db, const PlaceParam
         vlo2 = g2.x; vhi2 = g2.y; x2 = g2.z; wt2 = g2.w;
     }
     constexpr uint32_t CL = REG2 ? 2u : 1u;  // first chunk that stays in LDS
+    // MANY = false: the caller knows that every group is in the register chunks (nearly every 150 bp read): the copy of the
+    // descent without the LDS loops and without the three tests a level for them
+    const uint32_t n_loop = MANY ? n_chunks : 0u;
     uint32_t w_all = wt + wt2;  // sum of every group's weight, active or not: the constant of the level decision
 #pragma unroll 1
-    for (uint32_t c = CL; c < n_chunks; ++c) w_all += cx.stage[c * 64 + lane].w;
+    for (uint32_t c = CL; c < n_loop; ++c) w_all += cx.stage[c * 64 + lane].w;
     w_all = wave_sum(w_all);
     // ---- C. descent -----------------------------------------------------------------------------------
-    const uint32_t* __restrict__ half = db.postings;  // record x = 8-byte halves 2x (left part), 2x+1 (right part)
+    // record x = 8-byte halves 2x (left part), 2x+1 (right part).  Strictly binary trees read the copy with MASK halves
+    // (cls_device.h): a group whose part has become narrow holds its tips as bits of `x` (bit i = row lo + i; bit 31 of its
+    // weight word says so) and is narrowed by bit arithmetic from then on, no read.
+    constexpr bool MASKS = !POLY;
+    const uint32_t* __restrict__ half = (MASKS && db.postings2) ? db.postings2 : db.postings;
     const bool rm = prm.remove_intersection != 0;
     skids_t K{};  // polytomy trees: where the current clade's third .. fifth child start, fetched with its node record
     if (POLY) K = load_kids(db.kids, 0);
-#if CLS_DESCENT_SPEC >= 2
-    snode_pair_t C{};  // the two children of the current clade when it has exactly two: requested as soon as the clade is known
-    if ((P.s[7] >> 8) == 2) { C = load_node_pair(db.nodes, P.s[2]); if (STATS && lane == 0) ib += 64; }
-#endif
     int32_t iteration = 0;
     for (;;) {
         ++iteration;
@@ -1258,7 +1264,7 @@ __device__ __forceinline__ void descend_groups(const DbDev& db, const PlaceParam
                 walk4(vlo, vhi, x, wt);
                 if (REG2) walk4(vlo2, vhi2, x2, wt2);
 #pragma unroll 1
-                for (uint32_t c = CL; c < n_chunks; ++c) { const uint4 g = cx.stage[c * 64 + lane]; walk4(g.x, g.y, g.z, g.w); }
+                for (uint32_t c = CL; c < n_loop; ++c) { const uint4 g = cx.stage[c * 64 + lane]; walk4(g.x, g.y, g.z, g.w); }
                 cA = wave_sum(cA); cB = wave_sum(cB); oA = wave_sum(oA); oB = wave_sum(oB);
                 const uint32_t U = wave_sum(u_lane);
 #pragma unroll
@@ -1302,7 +1308,7 @@ __device__ __forceinline__ void descend_groups(const DbDev& db, const PlaceParam
                 walk(vlo, vhi, x, wt);
                 if (REG2) walk(vlo2, vhi2, x2, wt2);
 #pragma unroll 1
-                for (uint32_t c = CL; c < n_chunks; ++c) { const uint4 g = cx.stage[c * 64 + lane]; walk(g.x, g.y, g.z, g.w); }
+                for (uint32_t c = CL; c < n_loop; ++c) { const uint4 g = cx.stage[c * 64 + lane]; walk(g.x, g.y, g.z, g.w); }
                 const uint32_t U = wave_sum(u_lane);
                 wave_sync();
                 for (uint32_t base = 0; base < m; base += 64) {
@@ -1335,9 +1341,6 @@ __device__ __forceinline__ void descend_groups(const DbDev& db, const PlaceParam
             if (n_pass > 1 && n_best != 1) { write_record(out, r, CLS_INCONCLUSIVE, (int32_t)n_pass, 0, (uint32_t)iteration, pid); return; }
             P = load_node(nodes, best_row);
             K = load_kids(db.kids, best_row);
-#if CLS_DESCENT_SPEC >= 2
-            if ((P.s[7] >> 8) == 2) { C = load_node_pair(nodes, P.s[2]); if (STATS && lane == 0) ib += 64; }
-#endif
             if (STATS && lane == 0) ib += 32;
             if (P.s[3] == 0) {
                 write_record(out, r, CLS_IDENTITY_FOUND, best_one, best_rest, (uint32_t)iteration, ((uint64_t)P.s[5] << 32) | P.s[4]);
@@ -1360,7 +1363,7 @@ __device__ __forceinline__ void descend_groups(const DbDev& db, const PlaceParam
             enter(vlo, vhi, x);
             if (REG2) enter(vlo2, vhi2, x2);
 #pragma unroll 1
-            for (uint32_t c = CL; c < n_chunks; ++c) {
+            for (uint32_t c = CL; c < n_loop; ++c) {
                 uint4 g = cx.stage[c * 64 + lane];
                 enter(g.x, g.y, g.z);
                 cx.stage[c * 64 + lane] = g;
@@ -1371,11 +1374,6 @@ __device__ __forceinline__ void descend_groups(const DbDev& db, const PlaceParam
         // The level's two memory round trips are taken off its dependent chain (waves spent two thirds of their time
         // parked on them): a group of chunk 0 that has tips on both sides of a1 will need one half of its split record
         // whichever child wins, so the whole 16-byte record is requested NOW, before the counting and the reduction ...
-#if CLS_DESCENT_SPEC >= 1
-        const bool str_any0 = vlo < a1 && vhi >= a1;
-        const uint4 rec0 = ldx<uint4, ADDR32>(reinterpret_cast<const uint4*>(half), str_any0 ? x : 0u);  // {tip_prev, L, tip, R}
-        if (STATS && str_any0) ib += 16;
-#endif
         // (one, rest) of place_sequence.rs:369-395 with |R_c| = |U| - |only_c|, |R_c \ K_c| = |U| - |K_c|:
         //   one_a - rest_a = |only_a| - |only_b| = |K_a| - |K_b| = -(one_b - rest_b)   for either remove_intersection,
         // so exactly one child passes `one > rest` when the two differ and none when they tie: a level only
@@ -1394,20 +1392,20 @@ __device__ __forceinline__ void descend_groups(const DbDev& db, const PlaceParam
         count(vlo, vhi, wt);
         if (REG2) count(vlo2, vhi2, wt2);
 #pragma unroll 1
-        for (uint32_t c = CL; c < n_chunks; ++c) { const uint4 g = cx.stage[c * 64 + lane]; count(g.x, g.y, g.w); }
+        for (uint32_t c = CL; c < n_loop; ++c) { const uint4 g = cx.stage[c * 64 + lane]; count(g.x, g.y, g.w); }
         const int32_t diff_ab = (int32_t)(wave_sum(acc) - w_all);  // |K_a| - |K_b|
         // |K_a|, |K_b|, |K_a ^ K_b| of this level: only the level the descent ends at asks
         auto final_counts = [&](uint32_t& cnt_a, uint32_t& cnt_b, uint32_t& both) {
             uint32_t ca = 0, cb = 0, bo = 0;
             auto count3 = [&](uint32_t lo_, uint32_t hi_, uint32_t w) {
-                const uint32_t ina = w & mask_lt(lo_, a1);    // lo >= a0 for an active group
-                const uint32_t inb = w & ~mask_lt(hi_, a1);   // hi < end of the parent for an active one, 0 for an inactive one
+                const uint32_t ina = w & 0xFFFFFFu & mask_lt(lo_, a1);    // lo >= a0 for an active group
+                const uint32_t inb = w & 0xFFFFFFu & ~mask_lt(hi_, a1);   // hi < end of the parent for an active one, 0 for an inactive one
                 ca += ina; cb += inb; bo += ina & inb;        // (both are 0 or w)
             };
             count3(vlo, vhi, wt);
             if (REG2) count3(vlo2, vhi2, wt2);
 #pragma unroll 1
-            for (uint32_t c = CL; c < n_chunks; ++c) { const uint4 g = cx.stage[c * 64 + lane]; count3(g.x, g.y, g.w); }
+            for (uint32_t c = CL; c < n_loop; ++c) { const uint4 g = cx.stage[c * 64 + lane]; count3(g.x, g.y, g.w); }
             cnt_a = m == 0 ? 0u : wave_sum(ca);
             cnt_b = m < 2 ? 0u : wave_sum(cb);
             both = m < 2 ? 0u : wave_sum(bo);
@@ -1419,21 +1417,17 @@ __device__ __forceinline__ void descend_groups(const DbDev& db, const PlaceParam
             return;
         }
         const bool right = diff_ab < 0;
-        // ... and the chosen child's node record is requested before the narrowing, not waited for until after it
-        // (the narrowing of a read's last level is wasted work: one level in sixteen)
-#if CLS_DESCENT_SPEC >= 2
-#pragma unroll
-        for (int i = 0; i < 8; ++i) P.s[i] = right ? C.s[8 + i] : C.s[i];  // already here: no read on the way to the next level
-        if ((P.s[7] >> 8) == 2) { C = load_node_pair(db.nodes, P.s[2]); if (STATS && lane == 0) ib += 64; }
-        if (POLY) K = load_kids(db.kids, fc + (right ? 1u : 0u));
-        __builtin_amdgcn_sched_barrier(0);  // keep the requests up here (the scheduler sinks scalar loads to their first use)
+        // (Measured and rejected, C3: requesting chunk 0's whole split record before the counting, 6.87 against 6.79 ms; with both
+        // children's node records a level ahead as well, 7.18; waiting for the chosen child's record only after the split reads
+        // have been requested, 6.66 against 6.15 ms -- each costs more registers and scalar moves than the round trip it hides.)
+#ifdef CLS_EXP_HOT_NODES
+        P = load_node(db.nodes, (fc + (right ? 1u : 0u)) & 255u);  // (timing experiment: wrong placements)
 #else
         P = load_node(db.nodes, fc + (right ? 1u : 0u));
+#endif
         if (POLY) K = load_kids(db.kids, fc + (right ? 1u : 0u));
         __builtin_amdgcn_sched_barrier(0);  // keep the request up here (the scheduler sinks scalar loads to their first use)
         if (STATS && lane == 0) ib += 32;
-#endif
-#if !CLS_DESCENT_SPEC
         if (P.s[3] == 0) {  // no non-LEAF child below the chosen clade (update_introspection_node.rs:45-85)
             uint32_t cnt_a, cnt_b, both;
             final_counts(cnt_a, cnt_b, both);
@@ -1442,20 +1436,6 @@ __device__ __forceinline__ void descend_groups(const DbDev& db, const PlaceParam
                          ((uint64_t)P.s[5] << 32) | P.s[4]);
             return;
         }
-#else
-        {   // chunk 0 from the record requested above
-            const bool str = str_any0 && (right || vlo != a0);
-            if (!right) {
-                const bool gone = vlo >= a1 || vlo == a0;  // no tip strictly below the first child
-                if (str) { vhi = rec0.x; x = rec0.y; }
-                if (gone) { vlo = GRP_INACTIVE; vhi = 0; }
-            } else {
-                if (str) { vlo = rec0.z; x = rec0.w; }
-                const bool gone = vhi < a1 || vlo == a1;  // nothing in the second child, or it is the tip itself
-                if (gone) { vlo = GRP_INACTIVE; vhi = 0; }
-            }
-        }
-#endif
         // narrow: a set with tips on both sides of a1 reads 8 bytes of its split node (the half for the side
         // taken); everything else is arithmetic on (lo, hi).  Inactive afterwards = {MAX, 0}.
         // Two steps, so that the reads of the two register chunks are in flight together (as one step per chunk the
@@ -1463,57 +1443,67 @@ __device__ __forceinline__ void descend_groups(const DbDev& db, const PlaceParam
         // copy of the level per side (`right` is wave-uniform).
         auto narrow_side = [&](auto side) {
             constexpr bool RIGHT = decltype(side)::value;
-            auto request = [&](uint32_t lo_, uint32_t hi_, uint32_t x_, uint32_t& strm) -> uint2 {
-                const uint32_t lt = mask_lt(lo_, a1), ge = ~mask_lt(hi_, a1);  // a tip below a1 / a tip at or beyond a1
-                // tips on both sides (left: and one strictly below the first child)
-                strm = RIGHT ? (lt & ge) : (lt & ge & (lo_ != a0 ? ~0u : 0u));
-                if (STATS) ib += strm & 8u;
-                return ldx<uint2, ADDR32>(half, (2 * x_ + (RIGHT ? 1u : 0u)) & strm);  // (record 0: the dummy)
+            // (every value is below 2^31 and an active group has a0 <= lo <= hi: `u < v` is the sign of u - v, `lo != a0` that of a0 - lo)
+            // `aux`: left = the group keeps a tip strictly below the first child (known before the read comes back);
+            // right = the group has NO tip at or beyond a1.  `strm` = tips on both sides, `rd` = and the part is behind a read.
+            auto classify = [&](uint32_t lo_, uint32_t hi_, uint32_t w_, uint32_t& strm, uint32_t& rd, uint32_t& aux) {
+                const uint32_t lt = sign_mask(lo_ - a1), nge = sign_mask(hi_ - a1);  // a tip below a1 / NO tip at or beyond a1
+                if (!RIGHT) { aux = lt & sign_mask(a0 - lo_); strm = aux & ~nge; }   // tips on both sides, one strictly below the first child
+                else { aux = nge; strm = lt & ~nge; }                                  // tips on both sides
+                rd = MASKS ? (strm & ~sign_mask(w_)) : strm;
+                if (STATS) ib += rd & 8u;
             };
-            auto finish = [&](uint32_t& lo_, uint32_t& hi_, uint32_t& x_, uint32_t strm, uint2 t) {
-                x_ = (t.y & strm) | (x_ & ~strm);
+            auto request = [&](uint32_t x_, uint32_t rd) -> uint2 {
+                return ldx<uint2, ADDR32>(half, (2 * x_ + (RIGHT ? 1u : 0u)) & rd);  // (record 0: the dummy)
+            };
+            auto finish = [&](uint32_t& lo_, uint32_t& hi_, uint32_t& x_, uint32_t& w_, uint32_t strm, uint32_t rd, uint32_t aux, uint2 t) {
+                uint32_t end = t.x, xn = t.y;  // what the read gave: the new last (left) / first (right) tip, the part's split or bits
+                if (MASKS) {
+                    w_ |= t.x & rd & MASK_HALF;       // the part came as bits: the group is narrowed by arithmetic from here on
+                    end &= ~MASK_HALF;
+                    // a group that already holds bits: rows [lo, a1) are bits [0, d), d = a1 - lo in 1 .. 31 when it has tips on both sides
+                    const uint32_t d = a1 - lo_;
+                    uint32_t mend, mx;
+                    if (!RIGHT) { mx = x_ & ((1u << (d & 31u)) - 1u); mend = lo_ + 31u - (uint32_t)__clz((int)mx); }
+                    else { const uint32_t up = x_ >> (d & 31u); const uint32_t z = (uint32_t)__ffs((int)up) - 1u; mx = up >> (z & 31u); mend = a1 + z; }
+                    end = bfi(rd, end, mend);
+                    xn = bfi(rd, xn, mx);
+                }
+                x_ = bfi(strm, xn, x_);
                 uint32_t keep;
                 if (!RIGHT) {
-                    keep = mask_lt(lo_, a1) & (lo_ != a0 ? ~0u : 0u);           // a tip strictly below the first child
-                    hi_ = (t.x & strm) | (hi_ & ~strm);
+                    keep = aux;
+                    hi_ = bfi(strm, end, hi_);
                 } else {
-                    keep = ~mask_lt(hi_, a1);                                   // something in the second child ...
-                    lo_ = (t.x & strm) | (lo_ & ~strm);
-                    keep &= lo_ != a1 ? ~0u : 0u;                               // ... and not just the clade itself
+                    lo_ = bfi(strm, end, lo_);
+                    keep = sign_mask(a1 - lo_) & ~aux;  // something in the second child, and not just the clade itself
                 }
-                lo_ = (lo_ & keep) | (GRP_INACTIVE & ~keep);
+                lo_ = bfi(keep, lo_, GRP_INACTIVE);
                 hi_ &= keep;
             };
-            uint32_t s0 = 0, s1 = 0;
+            uint32_t s0 = 0, s1 = 0, r0 = 0, r1 = 0, k0 = 0, k1 = 0;
             uint2 t0{}, t1{};
-#if !CLS_DESCENT_SPEC
-            t0 = request(vlo, vhi, x, s0);
-#endif
-            if (REG2) t1 = request(vlo2, vhi2, x2, s1);
-#if !CLS_DESCENT_SPEC
-            finish(vlo, vhi, x, s0, t0);
-#endif
-            if (REG2) finish(vlo2, vhi2, x2, s1, t1);
+            classify(vlo, vhi, wt, s0, r0, k0);
+            if (REG2) classify(vlo2, vhi2, wt2, s1, r1, k1);
+            // (deep in the tree every group with tips on both sides holds bits: no read at all, and nothing to wait for)
+            if (!MASKS || __builtin_amdgcn_ballot_w64((r0 | r1) != 0u) != 0ull) {
+                t0 = request(x, r0);
+                if (REG2) t1 = request(x2, r1);
+                __builtin_amdgcn_sched_barrier(0);  // both reads on their way before either is waited for
+            }
+            finish(vlo, vhi, x, wt, s0, r0, k0, t0);
+            if (REG2) finish(vlo2, vhi2, x2, wt2, s1, r1, k1, t1);
 #pragma unroll 1
-            for (uint32_t c = CL; c < n_chunks; ++c) {
+            for (uint32_t c = CL; c < n_loop; ++c) {
                 uint4 g = cx.stage[c * 64 + lane];
-                uint32_t sm;
-                const uint2 t = request(g.x, g.y, g.z, sm);
-                finish(g.x, g.y, g.z, sm, t);
+                uint32_t sm, rm_, km;
+                classify(g.x, g.y, g.w, sm, rm_, km);
+                const uint2 t = request(g.z, rm_);
+                finish(g.x, g.y, g.z, g.w, sm, rm_, km, t);
                 cx.stage[c * 64 + lane] = g;
             }
         };
         if (right) narrow_side(std::true_type{}); else narrow_side(std::false_type{});
-#if CLS_DESCENT_SPEC
-        if (P.s[3] == 0) {  // no non-LEAF child below the chosen clade (update_introspection_node.rs:45-85)
-            uint32_t cnt_a, cnt_b, both;
-            final_counts(cnt_a, cnt_b, both);
-            const uint32_t cn = right ? cnt_b : cnt_a, on = cn - both, U = cnt_a + cnt_b - both;
-            write_record(out, r, CLS_IDENTITY_FOUND, (int32_t)(rm ? on : cn), (int32_t)(rm ? U - cn : U - on), (uint32_t)iteration,
-                         ((uint64_t)P.s[5] << 32) | P.s[4]);
-            return;
-        }
-#endif
     }
 }
 
@@ -1679,7 +1669,10 @@ __device__ __forceinline__ void place_read_fast(const DbDev& db, const PlacePara
         const uint64_t exp_usize = (expected != expected) ? 0ull : (uint64_t)expected;
         if ((uint64_t)n_root < exp_usize) { put_index_bytes(); write_record(out, r, CLS_UNCLASSIFIABLE_COVERAGE, (int32_t)n_root, 0, 0, 0); return; }
     }
-    descend_groups<ADDR32, POLY, STATS>(db, prm, cx, n_sets, P, r, out, ib);
+    bool in_registers = false;
+    if constexpr (!POLY) in_registers = uniform(n_sets) <= 128;  // (the binary descent keeps two chunks of 64 groups in registers)
+    if (in_registers) descend_groups<ADDR32, POLY, STATS, false>(db, prm, cx, n_sets, P, r, out, ib);
+    else descend_groups<ADDR32, POLY, STATS, true>(db, prm, cx, n_sets, P, r, out, ib);
     put_index_bytes();
 }
 

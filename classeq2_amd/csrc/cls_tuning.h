@@ -9,6 +9,7 @@ struct Tuning {
     int no_fast = 0;              // CLS_NO_FAST: generic kernels only
     int no_order = 0;             // CLS_NO_ORDER: no locality order
     int force_list = 0;           // CLS_FORCE_LIST: sorted-list postings even when every node set is closed
+    int no_mask_halves = 0;       // CLS_NO_MASK_HALVES: no second copy of the split records with narrow parts as bit masks (set before cls_db_create)
     int no_fat_direct = 0;        // CLS_NO_FAT_DIRECT: no denormalised 16-byte direct table for k <= 12 (set before cls_db_create)
     int no_tile = 0;              // CLS_NO_TILE: long reads through the workspace kernel only
     int tile_pass_codes = 1536;   // CLS_TILE_PASS_CODES: lookups per pass of the LDS-tiled kernel's 4096-entry code set (a huge
