@@ -288,6 +288,7 @@ int encode_db(const cls_db_desc* d, EncodedDb& E, std::string& err) {
         if (d->nodes[order[r]].n_children != 0 && d->nodes[order[r]].n_children != 2) { E.strictly_binary = false; break; }
     E.format = (n_closed.load() == NK && !tuning().force_list && N < DIRECT_TIP_MASK) ? FMT_SPLIT : FMT_LIST;
     std::vector<uint32_t> set_of;  // FMT_SPLIT: k-mer -> set id (>= 1)
+    std::vector<uint32_t> set_mask;  // MASK halves: per set its tips as bits relative to the first one, 0 if they span more than 32 rows
     if (E.format == FMT_SPLIT) {
         if (NK >= (1ULL << 32) - 1) { err = "more than 2^32 - 2 k-mers"; return CLS_E_BAD_DB; }
         auto words_of = [&](uint32_t j) { return &E.postings[kmer_off[j]]; };
@@ -396,7 +397,7 @@ int encode_db(const cls_db_desc* d, EncodedDb& E, std::string& err) {
         recs[2] = 0xFFFFFFFFu;  // dummy {0, 0, first tip = MAX, 0}: decodes to "inactive"
         const bool mask_halves = E.strictly_binary && !tuning().no_mask_halves;
         HugeVec<uint32_t> recs2(mask_halves ? (n_recs + 1) * 4 : 0, 0);
-        if (mask_halves) recs2[2] = 0xFFFFFFFFu;
+        if (mask_halves) { recs2[2] = 0xFFFFFFFFu; set_mask.assign(NS + 1, 0u); }
         E.sets.assign(NS + 1, SetRec{0u, 0xFFFFFFFFu, 0u, 0u});
         parallel_chunks(NS, nt, [&](unsigned, uint64_t lo, uint64_t hi) {
             std::vector<uint32_t> dd, stk, L, R, pos, span_lo, span_hi;
@@ -462,6 +463,11 @@ int encode_db(const cls_db_desc* d, EncodedDb& E, std::string& err) {
                             u[2] = tip[i] | MASK_HALF; u[3] = bits;
                         }
                     }
+                }
+                if (mask_halves && n && tip[n - 1] - tip[0] < MASK_HALF_SPAN) {
+                    uint32_t bits = 0;
+                    for (uint32_t j = 0; j < n; ++j) bits |= 1u << (tip[j] - tip[0]);
+                    set_mask[g + 1] = bits;
                 }
                 uint32_t lg = 0;
                 while (lg < 31 && (1u << lg) <= n) ++lg;  // bit length: small = specific to a small clade
@@ -583,6 +589,10 @@ int encode_db(const cls_db_desc* d, EncodedDb& E, std::string& err) {
                         const SetRec& sr = E.sets[e & SET_ID_MASK];  // (set 0: {0, MAX, 0, 0})
                         uint32_t* o = &E.direct16[4 * code];
                         o[0] = sr.x; o[1] = sr.vlo_lg; o[2] = sr.vhi_root; o[3] = e;
+                        // a set that spans at most 32 rows starts its descent as bits (only the wave-per-read kernels of
+                        // strictly binary trees read this table's x: cls_device.h, MASK halves)
+                        const uint32_t bits = set_mask.empty() ? 0u : set_mask[e & SET_ID_MASK];
+                        if (bits) { o[0] = bits; o[2] |= FAT_X_IS_BITS; }
                     }
                 });
             }

@@ -118,6 +118,7 @@ static_assert(sizeof(TipRec) == 16, "TipRec");
 // line from HBM), and with masks they are not read at all.
 constexpr uint32_t MASK_HALF = 0x80000000u;
 constexpr uint32_t MASK_HALF_SPAN = 32;
+constexpr uint32_t FAT_X_IS_BITS = 0x40000000u;  // direct16 entry, word 2: word 0 holds the set's tips as bits relative to its first tip
 
 enum : uint32_t { FMT_LIST = 0, FMT_SPLIT = 1 };
 

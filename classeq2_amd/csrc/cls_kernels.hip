@@ -1208,9 +1208,10 @@ __device__ __forceinline__ void descend_groups(const DbDev& db, const PlaceParam
     // MANY = false: the caller knows that every group is in the register chunks (nearly every 150 bp read): the copy of the
     // descent without the LDS loops and without the three tests a level for them
     const uint32_t n_loop = MANY ? n_chunks : 0u;
-    uint32_t w_all = wt + wt2;  // sum of every group's weight, active or not: the constant of the level decision
+    // sum of every group's weight, active or not: the constant of the level decision (bit 31 of a weight word: the group holds bits)
+    uint32_t w_all = (wt & 0xFFFFFFu) + (wt2 & 0xFFFFFFu);
 #pragma unroll 1
-    for (uint32_t c = CL; c < n_loop; ++c) w_all += cx.stage[c * 64 + lane].w;
+    for (uint32_t c = CL; c < n_loop; ++c) w_all += cx.stage[c * 64 + lane].w & 0xFFFFFFu;
     w_all = wave_sum(w_all);
     // ---- C. descent -----------------------------------------------------------------------------------
     // record x = 8-byte halves 2x (left part), 2x+1 (right part).  Strictly binary trees read the copy with MASK halves
@@ -1646,7 +1647,8 @@ __device__ __forceinline__ void place_read_fast(const DbDev& db, const PlacePara
             const bool live = ((owner >> s) & 1u) && sr[i].y != 0xFFFFFFFFu;
             const uint64_t m = __ballot(live);
             if (live)
-                cx.stage[n_sets + popc64(m & ((1ull << lane) - 1))] = uint4{sr[i].y & DIRECT_TIP_MASK, sr[i].z & 0x7FFFFFFFu, sr[i].x, w};
+                cx.stage[n_sets + popc64(m & ((1ull << lane) - 1))] = uint4{sr[i].y & DIRECT_TIP_MASK, sr[i].z & DIRECT_TIP_MASK, sr[i].x,
+                                                                              w | ((sr[i].z & FAT_X_IS_BITS) << 1)};  // (a narrow set comes as bits: MASK halves)
             n_sets += popc64(m);
         }
     }
