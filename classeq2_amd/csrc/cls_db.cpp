@@ -612,6 +612,64 @@ int encode_db(const cls_db_desc* d, EncodedDb& E, std::string& err) {
 
 }  // namespace cls
 
+// ---- host-side self-check of the MASK halves (tests/test_host_cpu.py; no device involved) ---------------------------
+// Every half of the second copy of the split records against the tips its part has ACCORDING TO THE FIRST COPY (walked
+// record by record): a MASK half's bits are exactly those tips relative to the part's first one, a plain half is
+// unchanged and leads to a part that spans more than 32 rows.  counts[0..2] = records, MASK halves, plain halves.
+// CLS_E_INTERNAL on the first mismatch.
+extern "C" int cls_db_debug_mask_halves(const cls_db_desc* d, uint64_t* counts) {
+    try {
+        cls::EncodedDb E;
+        std::string err;
+        const int rc = cls::encode_db(d, E, err);
+        if (rc != CLS_OK) return rc;
+        using namespace cls;
+        counts[0] = counts[1] = counts[2] = 0;
+        if (E.format != FMT_SPLIT || E.postings2.empty()) return CLS_OK;
+        if (E.postings2.size() != E.postings.size()) return CLS_E_INTERNAL;
+        const TipRec* recs = reinterpret_cast<const TipRec*>(E.postings.data());
+        const TipRec* rec2 = reinterpret_cast<const TipRec*>(E.postings2.data());
+        const uint64_t n_recs = E.postings.size() / 4;
+        // tips of the part a half {end tip, record} leads to, in order (side 0: the part ENDS at the tip, 1: it STARTS there)
+        std::function<void(uint32_t, uint32_t, int, std::vector<uint32_t>&)> part = [&](uint32_t end_tip, uint32_t x, int side, std::vector<uint32_t>& out) {
+            if (!x) { out.push_back(end_tip); return; }
+            const TipRec& t = recs[x];
+            part(t.tip_prev, t.l, 0, out);
+            part(t.tip, t.r, 1, out);
+            (void)side;
+        };
+        std::vector<uint32_t> tips;
+        for (uint64_t x = 1; x + 1 < n_recs; ++x) {  // (record 0: the dummy; the last one: the tail pad)
+            const TipRec& t = recs[x];
+            const TipRec& u = rec2[x];
+            if (t.tip_prev == 0 && t.tip == 0 && t.l == 0 && t.r == 0) continue;  // (unused tail)
+            ++counts[0];
+            for (int side = 0; side < 2; ++side) {
+                const uint32_t end_tip = side ? t.tip : t.tip_prev, sub = side ? t.r : t.l;
+                const uint32_t uw = side ? u.tip : u.tip_prev, ux = side ? u.r : u.l;
+                tips.clear();
+                part(end_tip, sub, side, tips);
+                if (!std::is_sorted(tips.begin(), tips.end()) || (side ? tips.front() : tips.back()) != end_tip) return CLS_E_INTERNAL;
+                const bool narrow = tips.back() - tips.front() < MASK_HALF_SPAN;
+                if (uw & MASK_HALF) {
+                    uint32_t bits = 0;
+                    for (uint32_t v : tips) bits |= 1u << (v - tips.front());
+                    if (!narrow || (uw & ~MASK_HALF) != end_tip || ux != bits) return CLS_E_INTERNAL;
+                    ++counts[1];
+                } else {
+                    if (narrow || uw != end_tip || ux != sub) return CLS_E_INTERNAL;
+                    ++counts[2];
+                }
+            }
+        }
+        return CLS_OK;
+    } catch (const std::bad_alloc&) {
+        return CLS_E_NOMEM;
+    } catch (...) {
+        return CLS_E_INTERNAL;
+    }
+}
+
 // ---- host-side self-check of the encoder (tests/test_host_cpu.py; no device involved) ----------------------------
 // For each probe (k-mer hash, clade id): is the clade in the k-mer's node set ACCORDING TO THE ENCODED INDEX?  Answered
 // the way the kernels do: hash table -> set / postings -> tips (every tip of a split tree is collected by walking

@@ -116,6 +116,8 @@ static_assert(sizeof(TipRec) == 16, "TipRec");
 // and every later narrowing of that group is bit arithmetic on `bits`.  The last four or five levels of a descent run
 // inside clades of at most 16 leaves: their split records are the ones hardly any other read asks for (every one a
 // line from HBM), and with masks they are not read at all.
+// (Measured and rejected: a third form for wider parts of at most three tips, {tip | flag, middle tip} -- on C3 the reads
+// asked for stayed at 748 a read against 746 and the kernel went from 5.35 to 5.6 ms: parts that wide have more tips.)
 constexpr uint32_t MASK_HALF = 0x80000000u;
 constexpr uint32_t MASK_HALF_SPAN = 32;
 constexpr uint32_t FAT_X_IS_BITS = 0x40000000u;  // direct16 entry, word 2: word 0 holds the set's tips as bits relative to its first tip

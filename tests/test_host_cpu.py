@@ -183,6 +183,26 @@ def test_encoded_index_answers_membership_like_the_node_sets(case):
     assert L.cls_db_debug_members(C.byref(d), absent.ctypes.data, ids[:3].copy().ctypes.data, 3, out.ctypes.data) == 0 and (out == 2).all()
 
 
+@pytest.mark.parametrize("case", [(300, 400, 9, 4, 0.0, 0), (200, 300, 8, 4, 0.0, 1), (120, 300, 12, 4, 0.0, 2), (100, 300, 9, 4, 0.3, 0)])
+def test_mask_halves_describe_the_same_tips(case):
+    """The second copy of the split records (strictly binary trees: parts that span at most 32 rows as bit masks) checked
+    on the host against the first copy, half by half (cls_db_debug_mask_halves); a tree with polytomies has no second copy."""
+    nl, rl, k, m, cp, deep = case
+    s = SynthDb(nl, rl, k, m, collapse_prob=cp, deep=deep, seed_tree=211, seed_refseq=212)
+    L = engine.lib()
+    L.cls_db_debug_mask_halves.argtypes = [C.POINTER(_abi.DbDesc), C.c_void_p]
+    L.cls_db_debug_mask_halves.restype = C.c_int
+    for flat in (s.flat, s.flat.to_leaves_only()):
+        counts = np.zeros(3, dtype=np.uint64)
+        d = flat.desc()
+        assert L.cls_db_debug_mask_halves(C.byref(d), counts.ctypes.data) == 0, counts
+        if cp == 0.0:
+            assert counts[0] > 0 and counts[1] > 0 and counts[2] > 0, counts
+            assert counts[1] + counts[2] == 2 * counts[0]
+        else:
+            assert (counts == 0).all(), counts
+
+
 def test_tuning_knobs_are_explicit():
     """Experiment knobs go through cls_set_tuning (the library reads no environment variable on its own): known names
     are accepted, unknown ones refused; cls_tuning_from_env is an explicit call."""
