@@ -395,7 +395,7 @@ int encode_db(const cls_db_desc* d, EncodedDb& E, std::string& err) {
         if (n_recs >= (1ULL << 32)) { err = "split trees exceed 2^32 records"; return CLS_E_BAD_DB; }
         HugeVec<uint32_t> recs((n_recs + 1) * 4, 0);
         recs[2] = 0xFFFFFFFFu;  // dummy {0, 0, first tip = MAX, 0}: decodes to "inactive"
-        const bool mask_halves = E.strictly_binary && !tuning().no_mask_halves;
+        const bool mask_halves = !tuning().no_mask_halves;
         HugeVec<uint32_t> recs2(mask_halves ? (n_recs + 1) * 4 : 0, 0);
         if (mask_halves) { recs2[2] = 0xFFFFFFFFu; set_mask.assign(NS + 1, 0u); }
         E.sets.assign(NS + 1, SetRec{0u, 0xFFFFFFFFu, 0u, 0u});

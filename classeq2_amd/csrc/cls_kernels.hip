@@ -1217,8 +1217,24 @@ __device__ __forceinline__ void descend_groups(const DbDev& db, const PlaceParam
     // record x = 8-byte halves 2x (left part), 2x+1 (right part).  Strictly binary trees read the copy with MASK halves
     // (cls_device.h): a group whose part has become narrow holds its tips as bits of `x` (bit i = row lo + i; bit 31 of its
     // weight word says so) and is narrowed by bit arithmetic from then on, no read.
-    constexpr bool MASKS = !POLY;
+    constexpr bool MASKS = true;
     const uint32_t* __restrict__ half = (MASKS && db.postings2) ? db.postings2 : db.postings;
+    // One step along a group's chain of occupied children at a polytomy: the first tip at or beyond `bound` (there is one:
+    // the caller saw hi >= bound) and what describes the tips from there on -- the right half of the group's split record
+    // (the Cartesian tree breaks ties to the left: that half IS "the first tip beyond this child, the split of the rest"),
+    // or, for a group that holds bits, a shift.
+    auto next_part = [&](uint32_t bound, uint32_t& v, uint32_t& xx, bool& bits) {
+        if (MASKS && bits) {
+            const uint32_t up = xx >> ((bound - v) & 31u);
+            const uint32_t z = (uint32_t)__ffs((int)up) - 1u;
+            v = bound + z; xx = up >> (z & 31u);
+        } else {
+            const uint2 t = ldx<uint2, ADDR32>(half, 2 * xx + 1);
+            if (STATS) ib += 8;
+            v = t.x & ~MASK_HALF; xx = t.y;
+            if (MASKS) bits = (t.x & MASK_HALF) != 0u;
+        }
+    };
     const bool rm = prm.remove_intersection != 0;
     skids_t K{};  // polytomy trees: where the current clade's third .. fifth child start, fetched with its node record
     if (POLY) K = load_kids(db.kids, 0);
@@ -1245,8 +1261,10 @@ __device__ __forceinline__ void descend_groups(const DbDev& db, const PlaceParam
                 const uint32_t B0 = P.s[0] + 1, B1 = P.s[6], B2 = K.s[0], B3 = K.s[1], B4 = K.s[2];
                 const uint32_t last_end = m == 0 ? B0 : m == 1 ? B1 : m == 2 ? B2 : m == 3 ? B3 : B4;  // end of the last non-LEAF child
                 uint32_t cA = 0, cB = 0, oA = 0, oB = 0, u_lane = 0;  // |K_0| | |K_1| << 16, |K_2| | |K_3| << 16; likewise |only_c|; |U|
-                auto walk4 = [&](uint32_t v, uint32_t vh, uint32_t xx, uint32_t w) {
+                auto walk4 = [&](uint32_t v, uint32_t vh, uint32_t xx, uint32_t wf) {
                     uint32_t nin = 0, which = 0;
+                    bool bits = (wf >> 31) != 0u;  // the group holds its tips as bits of xx (MASK halves)
+                    const uint32_t w = wf & 0xFFFFFFu;
                     while (v < last_end) {  // v lies under exactly one non-LEAF child
                         const uint32_t c = (v >= B1 ? 1u : 0u) + (v >= B2 ? 1u : 0u) + (v >= B3 ? 1u : 0u);
                         const uint32_t c_end = c == 0 ? B1 : c == 1 ? B2 : c == 2 ? B3 : B4;
@@ -1255,9 +1273,7 @@ __device__ __forceinline__ void descend_groups(const DbDev& db, const PlaceParam
                         if (nin == 0) which = c;
                         if (nin < 2) ++nin;
                         if (vh < c_end) break;                                         // no tip beyond this child
-                        const uint2 t = ldx<uint2, ADDR32>(half, 2 * xx + 1);          // first tip beyond it, the split of the rest
-                        if (STATS) ib += 8;
-                        v = t.x; xx = t.y;
+                        next_part(c_end, v, xx, bits);                                 // first tip beyond it, the split of the rest
                     }
                     if (nin == 1) { const uint32_t inc = w << (16 * (which & 1u)); if (which < 2) oA += inc; else oB += inc; }
                     u_lane += nin ? w : 0u;
@@ -1289,8 +1305,10 @@ __device__ __forceinline__ void descend_groups(const DbDev& db, const PlaceParam
                 if (lane == 0) cx.cpre[m] = last_end;
                 wave_sync();
                 uint32_t u_lane = 0;
-                auto walk = [&](uint32_t v, uint32_t vh, uint32_t xx, uint32_t w) {
+                auto walk = [&](uint32_t v, uint32_t vh, uint32_t xx, uint32_t wf) {
                     uint32_t nin = 0, which = 0;
+                    bool bits = (wf >> 31) != 0u;
+                    const uint32_t w = wf & 0xFFFFFFu;
                     while (v < last_end) {  // v lies under exactly one non-LEAF child: the last one that starts at or before it
                         uint32_t lo_ = 0, hi_ = m;
                         while (hi_ - lo_ > 1) { const uint32_t mid = (lo_ + hi_) >> 1; if (cx.cpre[mid] <= v) lo_ = mid; else hi_ = mid; }
@@ -1299,9 +1317,7 @@ __device__ __forceinline__ void descend_groups(const DbDev& db, const PlaceParam
                         if (nin == 0) which = lo_;
                         if (nin < 2) ++nin;
                         if (vh < c_end) break;                                         // no tip beyond this child
-                        const uint2 t = ldx<uint2, ADDR32>(half, 2 * xx + 1);          // first tip beyond it, the split of the rest
-                        if (STATS) ib += 8;
-                        v = t.x; xx = t.y;
+                        next_part(c_end, v, xx, bits);                                 // first tip beyond it, the split of the rest
                     }
                     if (nin == 1) atomicAdd(&cx.conly[which], w);
                     u_lane += nin ? w : 0u;
@@ -1349,24 +1365,32 @@ __device__ __forceinline__ void descend_groups(const DbDev& db, const PlaceParam
             }
             // enter the chosen child [c0, c_end): step past the occupied children before it, keep the part inside it
             const uint32_t c0 = P.s[0], c_end = c0 + P.s[1];
-            auto enter = [&](uint32_t& v, uint32_t& vh, uint32_t& xx) {
+            auto enter = [&](uint32_t& v, uint32_t& vh, uint32_t& xx, uint32_t& wf) {
                 bool dead = v > vh;
+                bool bits = (wf >> 31) != 0u;
                 while (!dead && v < c0) {
                     if (vh < c0) { dead = true; break; }
-                    const uint2 t = ldx<uint2, ADDR32>(half, 2 * xx + 1);
-                    if (STATS) ib += 8;
-                    v = t.x; xx = t.y;
+                    next_part(bits ? c0 : 0u, v, xx, bits);  // (a group that holds bits goes straight to its first tip inside the clade)
                 }
                 if (!dead && v < c_end && v != c0) {  // a tip strictly below the chosen clade
-                    if (vh >= c_end) { const uint2 t = ldx<uint2, ADDR32>(half, 2 * xx); vh = t.x; xx = t.y; if (STATS) ib += 8; }
+                    if (vh >= c_end) {                // ... and tips beyond it: keep the part inside
+                        if (MASKS && bits) { xx &= (1u << ((c_end - v) & 31u)) - 1u; vh = v + 31u - (uint32_t)__clz((int)xx); }
+                        else {
+                            const uint2 t = ldx<uint2, ADDR32>(half, 2 * xx);
+                            if (STATS) ib += 8;
+                            vh = t.x & ~MASK_HALF; xx = t.y;
+                            if (MASKS) bits = (t.x & MASK_HALF) != 0u;
+                        }
+                    }
                 } else { v = GRP_INACTIVE; vh = 0; }
+                if (MASKS) wf = (wf & 0xFFFFFFu) | (bits ? MASK_HALF : 0u);
             };
-            enter(vlo, vhi, x);
-            if (REG2) enter(vlo2, vhi2, x2);
+            enter(vlo, vhi, x, wt);
+            if (REG2) enter(vlo2, vhi2, x2, wt2);
 #pragma unroll 1
             for (uint32_t c = CL; c < n_loop; ++c) {
                 uint4 g = cx.stage[c * 64 + lane];
-                enter(g.x, g.y, g.z);
+                enter(g.x, g.y, g.z, g.w);
                 cx.stage[c * 64 + lane] = g;
             }
             continue;

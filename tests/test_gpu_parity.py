@@ -373,3 +373,29 @@ def test_slim_and_denormalised_direct_tables_agree(k, collapse, trunc):
             _check(flat, bases, offsets, kw, threads=16)
     finally:
         engine.set_tuning("no_fat_direct", 0)
+
+
+@pytest.mark.parametrize("k,deep,trunc,collapse", [(12, 0, False, 0.0), (12, 2, False, 0.0), (11, 0, True, 0.0), (14, 1, False, 0.0), (17, 0, False, 0.0),
+                                                   (12, 0, False, 0.3), (10, 0, True, 0.5), (35, 0, False, 0.3), (12, 1, False, 0.8)])
+def test_mask_halves_on_and_off_agree(k, deep, trunc, collapse):
+    """The wave-per-read kernels read a second copy of the split records in which parts that span at most 32 rows are bit
+    masks (and, for k <= 12, narrow sets start as bits straight from the fat direct table); with the knob off they walk
+    the plain records.  Both against the oracle: fat / slim direct table and hashed front, balanced and ladder-like trees,
+    binary trees and polytomies (small and large arities), node sets cut back so that some tips are internal clades."""
+    s = SynthDb(400, 900, k, 4, collapse_prob=collapse, deep=deep, seed_tree=31, seed_refseq=32)
+    flat = truncate_random_sets(s.flat, 0.05, seed=8) if trunc else s.flat
+    rng = np.random.default_rng(29)
+    bases, offsets = ragged_reads(rng, s, 6000, 60, 480, lower_frac=0.02)
+    with engine.PlacementDb(flat, device=0) as db:
+        assert db.info.binary_tree == (1 if collapse == 0.0 else 0)
+        with_masks = db.info.hbm_bytes
+    for kw in (dict(), dict(remove_intersection=True)):
+        _check(flat, bases, offsets, kw, threads=16)
+    engine.set_tuning("no_mask_halves", 1)
+    try:
+        with engine.PlacementDb(flat, device=0) as db:
+            assert db.info.hbm_bytes < with_masks
+        for kw in (dict(), dict(remove_intersection=True)):
+            _check(flat, bases, offsets, kw, threads=16)
+    finally:
+        engine.set_tuning("no_mask_halves", 0)

@@ -185,8 +185,8 @@ def test_encoded_index_answers_membership_like_the_node_sets(case):
 
 @pytest.mark.parametrize("case", [(300, 400, 9, 4, 0.0, 0), (200, 300, 8, 4, 0.0, 1), (120, 300, 12, 4, 0.0, 2), (100, 300, 9, 4, 0.3, 0)])
 def test_mask_halves_describe_the_same_tips(case):
-    """The second copy of the split records (strictly binary trees: parts that span at most 32 rows as bit masks) checked
-    on the host against the first copy, half by half (cls_db_debug_mask_halves); a tree with polytomies has no second copy."""
+    """The second copy of the split records (parts that span at most 32 rows as bit masks) checked on the host against
+    the first copy, half by half (cls_db_debug_mask_halves); binary trees and trees with polytomies."""
     nl, rl, k, m, cp, deep = case
     s = SynthDb(nl, rl, k, m, collapse_prob=cp, deep=deep, seed_tree=211, seed_refseq=212)
     L = engine.lib()
@@ -196,11 +196,8 @@ def test_mask_halves_describe_the_same_tips(case):
         counts = np.zeros(3, dtype=np.uint64)
         d = flat.desc()
         assert L.cls_db_debug_mask_halves(C.byref(d), counts.ctypes.data) == 0, counts
-        if cp == 0.0:
-            assert counts[0] > 0 and counts[1] > 0 and counts[2] > 0, counts
-            assert counts[1] + counts[2] == 2 * counts[0]
-        else:
-            assert (counts == 0).all(), counts
+        assert counts[0] > 0 and counts[1] > 0 and counts[2] > 0, counts
+        assert counts[1] + counts[2] == 2 * counts[0]
 
 
 def test_tuning_knobs_are_explicit():
