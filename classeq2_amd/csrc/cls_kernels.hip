@@ -2855,9 +2855,15 @@ PlacePlan plan_place(const DbDev& db, uint32_t n_reads, uint32_t n_cu, bool stat
             int per_cu = tuning().key_blocks_per_cu;
             const uint32_t ac = ascii_cap_of(db, 0);
             const size_t smem_k = (size_t)WAVES_PER_BLOCK * (ac + (db.direct ? 4u * (((ac >> 4) + 2 + 3) & ~3u) : 0u) + 16u);
-            const void* kfn = fast_mode(db) == 2 ? (const void*)order_key_kernel<CLS_SLOTS[0], true, true, true>
-                              : db.addr32 ? (const void*)order_key_kernel<CLS_SLOTS[0], true, true, false> : (const void*)order_key_kernel<CLS_SLOTS[0], false, true, false>;
+            // (the instance the default knobs launch: forward windows only, at most 64 of them -- two slots, not the placement kernel's five)
+            const bool two_slots = !tuning().order_both_strands && tuning().order_windows <= 64;
+            const void* kfn = fast_mode(db) == 2 ? (two_slots ? (const void*)order_key_kernel<2, true, true, true> : (const void*)order_key_kernel<CLS_SLOTS[0], true, true, true>)
+                              : db.addr32 ? (two_slots ? (const void*)order_key_kernel<2, true, true, false> : (const void*)order_key_kernel<CLS_SLOTS[0], true, true, false>)
+                                          : (two_slots ? (const void*)order_key_kernel<2, false, true, false> : (const void*)order_key_kernel<CLS_SLOTS[0], false, true, false>);
             if (per_cu <= 0 && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kfn, 64 * WAVES_PER_BLOCK, smem_k) != hipSuccess || per_cu <= 0)) per_cu = 4;
+            // (MurmurHash3 front: waves finish their reads at very different times; twice the resident grid evens the tail
+            // out: C3s35 keys 2.7 -> 2.1 ms)
+            if (tuning().key_blocks_per_cu <= 0 && fast_mode(db) == 2) per_cu *= 2;
             p.grid_key = std::max<uint32_t>(1, std::min<uint32_t>(want, n_cu * (uint32_t)per_cu));
         }
         p.keys_off_words = w;
