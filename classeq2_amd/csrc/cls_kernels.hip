@@ -37,10 +37,14 @@ constexpr int WAVES_PER_BLOCK = 4;
 #define MIN_WAVES_PER_EU 4
 #endif
 #ifndef FAST_MIN_WAVES
-#define FAST_MIN_WAVES 5  // 96 VGPRs: 5 workgroups per CU measured best on C3 (4: 9.2 ms, 5: 8.5, 6: 9.1 with more spills)
+#define FAST_MIN_WAVES 5  // 96 VGPRs: 5 workgroups per CU measured best on C3 (4: 9.2 ms, 5: 8.5, 6: 9.1 with more spills;
+                          // with MASK halves: 4: 5.48 ms, 5: 5.34, 6: 5.80)
 #endif
 #ifndef CLS_NARROW_CANON_BITS
 #define CLS_NARROW_CANON_BITS 9  // LDS tables of the narrow class on a strand-symmetric index (at most 160 lookups per read): 2^bits entries
+#endif
+#ifndef FAST_MIN_WAVES_POLY
+#define FAST_MIN_WAVES_POLY 4  // the polytomy kernels keep more state: at 96 VGPRs they spill 34 of them (C3s12: 5: 12.3 ms, 4: 11.95, 6: 13.4)
 #endif
 #ifndef FAST_MIN_WAVES_WIDE
 #define FAST_MIN_WAVES_WIDE 4  // the 16-slot class keeps more state per lane: forcing 96 VGPRs on it spills 74 of them
@@ -1703,7 +1707,7 @@ __device__ __forceinline__ void place_read_fast(const DbDev& db, const PlacePara
 }
 
 template <int SLOTS, int SET_BITS, bool STATS, bool ADDR32, int MODE, bool POLY>
-__global__ __launch_bounds__(64 * WAVES_PER_BLOCK, SLOTS <= 5 ? FAST_MIN_WAVES : FAST_MIN_WAVES_WIDE) void place_fast_kernel(
+__global__ __launch_bounds__(64 * WAVES_PER_BLOCK, SLOTS > 5 ? FAST_MIN_WAVES_WIDE : POLY ? FAST_MIN_WAVES_POLY : FAST_MIN_WAVES) void place_fast_kernel(
     DbDev db, PlaceParams prm, const uint8_t* __restrict__ bases, const uint64_t* __restrict__ offsets,
     const uint32_t* __restrict__ list, const uint32_t* __restrict__ list_len, uint32_t list_n, uint32_t xcd_chunks,
     cls_placement* __restrict__ out, cls_query_stats* __restrict__ stats, uint32_t ascii_cap, uint32_t profile_stop) {
