@@ -1192,7 +1192,7 @@ __device__ __forceinline__ uint32_t bfi(uint32_t m, uint32_t a, uint32_t b) { re
 // VGPRs and 8 waves per SIMD -- was measured: 7.4 ms against 6.85 ms fused on C3; more reads in flight do not pay for
 // writing and re-reading 1.6 GB of groups.)
 // STATS: `ib` accumulates (per lane) the index bytes the descent asks for: 32 per node record, 8 per split half.
-template <bool ADDR32, bool POLY, bool STATS, bool MANY>
+template <bool ADDR32, bool POLY, bool STATS, bool MANY, bool REG2>
 __device__ __forceinline__ void descend_groups(const DbDev& db, const PlaceParams& prm, const FastCtx& cx, uint32_t n_sets, snode_t P,
                                                uint32_t r, cls_placement* __restrict__ out, uint32_t& ib) {
     const uint32_t lane = threadIdx.x & 63;
@@ -1201,7 +1201,8 @@ __device__ __forceinline__ void descend_groups(const DbDev& db, const PlaceParam
     wave_sync();
     uint32_t vlo, vhi, x, wt;      // chunk 0 and ...
     uint32_t vlo2, vhi2, x2, wt2;  // ... chunk 1 live in registers (a 150 bp read has 70-140 groups): no LDS traffic, no loop for them
-    constexpr bool REG2 = !POLY;   // (the polytomy kernels have no registers to spare: they keep chunk 1 in LDS)
+    // (REG2: not for the polytomy kernels with the MurmurHash3 front -- C3s35 66.2 against 67.8 M placements/s with it,
+    // C3s12 (direct table) 79.5 against 76.7)
     {
         const uint4 g = n_chunks ? cx.stage[lane] : uint4{GRP_INACTIVE, 0u, 0u, 0u};
         vlo = g.x; vhi = g.y; x = g.z; wt = g.w;
@@ -1701,8 +1702,9 @@ __device__ __forceinline__ void place_read_fast(const DbDev& db, const PlacePara
     }
     bool in_registers = false;
     if constexpr (!POLY) in_registers = uniform(n_sets) <= 128;  // (the binary descent keeps two chunks of 64 groups in registers)
-    if (in_registers) descend_groups<ADDR32, POLY, STATS, false>(db, prm, cx, n_sets, P, r, out, ib);
-    else descend_groups<ADDR32, POLY, STATS, true>(db, prm, cx, n_sets, P, r, out, ib);
+    constexpr bool REG2 = !POLY || MODE != 2;
+    if (in_registers) descend_groups<ADDR32, POLY, STATS, false, REG2>(db, prm, cx, n_sets, P, r, out, ib);
+    else descend_groups<ADDR32, POLY, STATS, true, REG2>(db, prm, cx, n_sets, P, r, out, ib);
     put_index_bytes();
 }
 
