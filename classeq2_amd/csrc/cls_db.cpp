@@ -589,8 +589,8 @@ int encode_db(const cls_db_desc* d, EncodedDb& E, std::string& err) {
                         const SetRec& sr = E.sets[e & SET_ID_MASK];  // (set 0: {0, MAX, 0, 0})
                         uint32_t* o = &E.direct16[4 * code];
                         o[0] = sr.x; o[1] = sr.vlo_lg; o[2] = sr.vhi_root; o[3] = e;
-                        // a set that spans at most 32 rows starts its descent as bits (only the wave-per-read kernels of
-                        // strictly binary trees read this table's x: cls_device.h, MASK halves)
+                        // a set that spans at most 32 rows starts its descent as bits (only the wave-per-read kernels read
+                        // this table's x: cls_device.h, MASK halves)
                         const uint32_t bits = set_mask.empty() ? 0u : set_mask[e & SET_ID_MASK];
                         if (bits) { o[0] = bits; o[2] |= FAT_X_IS_BITS; }
                     }

@@ -40,7 +40,7 @@ struct EncodedDb {
     std::vector<DNode> nodes;
     std::vector<uint32_t> kids;       // 4 words per node: where its 3rd / 4th / 5th child starts (cls_device.h)
     HugeVec<Slot> table;              // FMT_LIST: Slot; FMT_SPLIT: TSlot (same size)
-    HugeVec<uint32_t> postings2;      // FMT_SPLIT, strictly binary tree: the split records again, narrow parts as bit masks (cls_device.h)
+    HugeVec<uint32_t> postings2;      // FMT_SPLIT: the split records again, narrow parts as bit masks (cls_device.h)
     HugeVec<uint32_t> postings;       // FMT_LIST words, or FMT_SPLIT split records (4 words each)
     uint32_t format = FMT_LIST;
     bool strictly_binary = false;

@@ -109,7 +109,7 @@ struct TipRec {
     uint32_t r;         // split of the right part
 };
 static_assert(sizeof(TipRec) == 16, "TipRec");
-// MASK halves (DbDev.postings2, the wave-per-read kernel on strictly binary trees): a part (left or right of a split) whose
+// MASK halves (DbDev.postings2, the wave-per-read kernels): a part (left or right of a split) whose
 // tips span at most 32 pre-order rows is not walked through further split records: the half that leads into it is
 //   {tip_prev | MASK_HALF, bits}   (left part; bit i = row (first tip of the part) + i is a tip; bit 0 is always set)
 //   {tip      | MASK_HALF, bits}   (right part; bit i = row tip + i is a tip)
@@ -131,7 +131,7 @@ struct DbDev {
                                 // non-LEAF children, so that a small polytomy is scored from two scalar loads
     const Slot* table;          // FMT_LIST: Slot; FMT_SPLIT: TSlot (same size, same probe sequence)
     const uint32_t* postings;   // FMT_LIST: u32 words; FMT_SPLIT: TipRec split records (16-byte units)
-    const uint32_t* postings2;  // FMT_SPLIT, strictly binary tree: the same records, same numbering, with MASK halves (below), or nullptr
+    const uint32_t* postings2;  // FMT_SPLIT: the same records, same numbering, with MASK halves (above), or nullptr (knob no_mask_halves)
     const uint64_t* bucket_key;
     const uint32_t* direct;     // FMT_SPLIT, k <= DIRECT_MAX_K: 4^k set ids, or nullptr
     const uint32_t* direct16;   // k <= FAT_DIRECT_MAX_K: the same table with the set record inside the entry (below), or nullptr

@@ -1219,7 +1219,7 @@ __device__ __forceinline__ void descend_groups(const DbDev& db, const PlaceParam
     for (uint32_t c = CL; c < n_loop; ++c) w_all += cx.stage[c * 64 + lane].w & 0xFFFFFFu;
     w_all = wave_sum(w_all);
     // ---- C. descent -----------------------------------------------------------------------------------
-    // record x = 8-byte halves 2x (left part), 2x+1 (right part).  Strictly binary trees read the copy with MASK halves
+    // record x = 8-byte halves 2x (left part), 2x+1 (right part).  The wave-per-read kernels read the copy with MASK halves
     // (cls_device.h): a group whose part has become narrow holds its tips as bits of `x` (bit i = row lo + i; bit 31 of its
     // weight word says so) and is narrowed by bit arithmetic from then on, no read.
     constexpr bool MASKS = true;
