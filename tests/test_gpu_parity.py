@@ -391,6 +391,8 @@ def test_mask_halves_on_and_off_agree(k, deep, trunc, collapse):
         with_masks = db.info.hbm_bytes
     for kw in (dict(), dict(remove_intersection=True)):
         _check(flat, bases, offsets, kw, threads=16)
+    if not trunc:  # the same index handed over as its leaves-only view (the node sets of the internal clades are implied)
+        _check(flat.to_leaves_only(), bases, offsets, {}, threads=16)
     engine.set_tuning("no_mask_halves", 1)
     try:
         with engine.PlacementDb(flat, device=0) as db:
