@@ -95,6 +95,7 @@ struct cls_db {
     void* d_direct = nullptr;
     void* d_direct16 = nullptr;
     void* d_sets = nullptr;
+    void* d_sets2 = nullptr;
     std::mutex ws_mu;
     uint64_t max_read_len = 0;  // what the device-buffer entry provisions its long-read slices for (0: none, reads of up to
                                 // MAX_READ_KMERS k-mers only; cls_db_set_max_read_len opts in)
@@ -177,6 +178,7 @@ extern "C" void cls_db_destroy(cls_db* db) {
     if (db->d_direct) (void)hipFree(db->d_direct);
     if (db->d_direct16) (void)hipFree(db->d_direct16);
     if (db->d_sets) (void)hipFree(db->d_sets);
+    if (db->d_sets2) (void)hipFree(db->d_sets2);
     if (have_prev) (void)hipSetDevice(prev);
     delete db;
 }
@@ -215,7 +217,8 @@ extern "C" int cls_db_create(const cls_db_desc* d, int device, cls_db** out) {
             (e = up(&db->d_bucket_key, E.bucket_key.data(), E.bucket_key.size() * 8)) != hipSuccess ||
             (!E.direct.empty() && (e = up(&db->d_direct, E.direct.data(), E.direct.size() * 4)) != hipSuccess) ||
             (!E.direct16.empty() && (e = up(&db->d_direct16, E.direct16.data(), E.direct16.size() * 4)) != hipSuccess) ||
-            (!E.sets.empty() && (e = up(&db->d_sets, E.sets.data(), E.sets.size() * sizeof(cls::SetRec))) != hipSuccess)) {
+            (!E.sets.empty() && (e = up(&db->d_sets, E.sets.data(), E.sets.size() * sizeof(cls::SetRec))) != hipSuccess) ||
+            (!E.sets2.empty() && (e = up(&db->d_sets2, E.sets2.data(), E.sets2.size() * sizeof(cls::SetRec))) != hipSuccess)) {
             cls_db_destroy(db);
             return fail(e == hipErrorOutOfMemory ? CLS_E_NOMEM : CLS_E_HIP, std::string("cls_db_create: upload failed: ") + hipGetErrorString(e));
         }
@@ -229,6 +232,7 @@ extern "C" int cls_db_create(const cls_db_desc* d, int device, cls_db** out) {
         v.direct = (const uint32_t*)db->d_direct;
         v.direct16 = (const uint32_t*)db->d_direct16;
         v.sets = (const cls::SetRec*)db->d_sets;
+        v.sets2 = (const cls::SetRec*)db->d_sets2;
         v.table_mask = E.table.size() - 1;
         v.n_nodes = (uint32_t)E.nodes.size();
         v.n_buckets = (uint32_t)E.bucket_key.size();
@@ -253,7 +257,7 @@ extern "C" int cls_db_create(const cls_db_desc* d, int device, cls_db** out) {
         i.n_closed_kmers = E.n_closed;
         i.table_slots = E.table.size();
         i.postings_words = E.postings.size();
-        i.hbm_bytes = E.nodes.size() * sizeof(cls::DNode) + E.table.size() * sizeof(cls::Slot) + (E.postings.size() + E.postings2.size()) * 4 + E.bucket_key.size() * 8 + E.direct.size() * 4 + E.direct16.size() * 4 + E.sets.size() * sizeof(cls::SetRec);
+        i.hbm_bytes = E.nodes.size() * sizeof(cls::DNode) + E.table.size() * sizeof(cls::Slot) + (E.postings.size() + E.postings2.size()) * 4 + E.bucket_key.size() * 8 + E.direct.size() * 4 + E.direct16.size() * 4 + (E.sets.size() + E.sets2.size()) * sizeof(cls::SetRec);
         i.max_read_kmers = (uint32_t)std::max<uint64_t>(cls::MAX_READ_KMERS, 2 * db->max_read_len);
         i.device = device;
         i.format = E.format;

@@ -480,6 +480,13 @@ int encode_db(const cls_db_desc* d, EncodedDb& E, std::string& err) {
         });
         E.postings.swap(recs);
         E.postings2.swap(recs2);
+        if (mask_halves) {  // the set records again, narrow sets as bits (the fronts without the fat direct table read these)
+            E.sets2.assign(E.sets.begin(), E.sets.end());
+            parallel_chunks(NS + 1, nt, [&](unsigned, uint64_t lo, uint64_t hi) {
+                for (uint64_t g = lo; g < hi; ++g)
+                    if (set_mask[g]) { E.sets2[g].x = set_mask[g]; E.sets2[g].vhi_root |= FAT_X_IS_BITS; }
+            });
+        }
         lap("split trees");
     }
     // ---- 5. hash table (linear probing; parallel claims, then a duplicate check) -------------------------

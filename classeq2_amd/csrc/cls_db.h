@@ -47,6 +47,7 @@ struct EncodedDb {
     bool canonical = false;           // direct table symmetric under reverse complement
     std::vector<uint64_t> bucket_key;
     HugeVec<SetRec> sets;             // FMT_SPLIT: tip sets (entry 0 = "no such k-mer")
+    HugeVec<SetRec> sets2;            // the same for the wave-per-read kernels: a set that spans at most 32 rows carries its bits (MASK halves)
     HugeVec<uint32_t> direct;         // 4^k set ids (FMT_SPLIT, k <= DIRECT_MAX_K) or empty
     HugeVec<uint32_t> direct16;       // 4^k x 4 words: set record + set id (k <= FAT_DIRECT_MAX_K) or empty
     uint32_t k = 0, m = 0, m_eff = 0;

@@ -136,6 +136,8 @@ struct DbDev {
     const uint32_t* direct;     // FMT_SPLIT, k <= DIRECT_MAX_K: 4^k set ids, or nullptr
     const uint32_t* direct16;   // k <= FAT_DIRECT_MAX_K: the same table with the set record inside the entry (below), or nullptr
     const SetRec* sets;         // FMT_SPLIT: tip sets
+    const SetRec* sets2;        // the same with x = the set's tips as bits and FAT_X_IS_BITS in word 2 where it spans at most 32 rows
+                                // (read by the wave-per-read kernels without the fat direct table), or nullptr
     uint64_t table_mask;
     uint32_t n_nodes;
     uint32_t n_buckets;

@@ -1645,7 +1645,7 @@ __device__ __forceinline__ void place_read_fast(const DbDev& db, const PlacePara
     // ---- A3. the owners read their set records; |M_root|; the groups that have tips below the root are compacted
     // into the staging area (64 per chunk; chunk 0 then lives in registers, the others stay in LDS).  A few records
     // in flight at a time: the wide class would otherwise hold 16 of them per lane in registers.
-    const uint4* __restrict__ sets = reinterpret_cast<const uint4*>(db.sets);
+    const uint4* __restrict__ sets = reinterpret_cast<const uint4*>(db.sets2 ? db.sets2 : db.sets);  // (narrow sets as bits: MASK halves)
     uint32_t cnt = nm_lane;  // |M| in bits 0..15, |M_root| in bits 16..31 (per lane, then summed)
     uint64_t leafp = 0;
     uint32_t n_sets = 0;
