@@ -2386,7 +2386,7 @@ struct TileSh {
 __host__ __device__ inline uint32_t tile_packed_words(uint32_t max_bases) { return ((max_bases + 15) / 16 + 2 + 3) & ~3u; }
 // dynamic LDS of the tile kernel for reads of up to `max_lookups` table lookups and `max_bases` bases
 __host__ __device__ inline size_t tile_smem(uint32_t max_lookups, uint32_t max_bases) {
-    return 4ull * tile_packed_words(max_bases) + 8ull * TILE_SET_ENTRIES + 8ull * max_lookups + 4ull * max_lookups + 16;
+    return 4ull * tile_packed_words(max_bases) + 4ull * TILE_SET_ENTRIES + 8ull * max_lookups + 4ull * max_lookups + 16;
 }
 
 template <int THREADS, bool CANON, bool STATS, bool ADDR32>
@@ -2402,7 +2402,6 @@ __global__ __launch_bounds__(THREADS) void place_tile_kernel(DbDev db, PlacePara
     uint64_t* const hot = reinterpret_cast<uint64_t*>(cset + TILE_SET_ENTRIES);   // {first tip : 24, last tip : 24, weight : 16}
     uint32_t* const xs = reinterpret_cast<uint32_t*>(hot + max_lookups);           // root split of the entry's set
     uint32_t* const wsid = xs;  // front only: per window its tip-set id | palindrome << 31 if it is the first with its code, else 0
-    uint32_t* const cval = xs + max_lookups;  // front only: per slot of the table of set ids (cset, second use) the k-mers of that set
     const uint32_t tid = threadIdx.x, lane = tid & 63;
     const uint32_t k = db.k;
     const uint32_t kmask = (1u << (2 * k)) - 1u;  // k <= 15
@@ -2499,32 +2498,15 @@ __global__ __launch_bounds__(THREADS) void place_tile_kernel(DbDev db, PlacePara
             if (tid == 0) spill_list[atomicAdd(spill_len, 1u)] = r;
             continue;
         }
-        // ---- A2b. state entries: ONE per distinct tip set.  Consecutive windows mostly share their tip set (a set's k-mers
-        // are the windows between two mutation boundaries of a lineage): a run of equal set ids among a wavefront's 64
-        // consecutive windows is summed first, then every run adds its weight to its set's slot in an LDS table keyed by
-        // the set id (the table of codes, free by now) -- the same set comes back all along a read (the k-mers only the
-        // read's own leaf has, those it shares with its sister, ...).  The entries are then made from the table: one
-        // 16-byte set record per distinct set, and fewer entries for every level of the descent to go through.  A run that
-        // finds no slot within a few probes becomes an entry of its own, as every run used to. ---------------------------
-        for (uint32_t i = tid; i < TILE_SET_ENTRIES; i += THREADS) { cset[i] = SET_EMPTY; cval[i] = 0u; }
+        // ---- A2b. state entries.  Consecutive windows mostly share their tip set (a set's k-mers are the windows between
+        // two mutation boundaries of a lineage): runs of equal set ids among a wavefront's 64 consecutive windows
+        // become ONE entry weighted by the run, and only the run's head reads the 16-byte set record. --------------
         uint32_t nm_t = 0, nroot_t = 0;
         uint64_t leafp_t = 0;
-        auto add_entry = [&](bool member, uint32_t sid, uint32_t w) {  // (every thread of the wavefront calls it: append_slot)
-            uint4 sr = uint4{0u, 0xFFFFFFFFu, 0u, 0u};
-            if (member) { sr = ldx<uint4, ADDR32>(sets, sid); if (STATS) ib_t += 16; }
-            const bool has_root = (sr.z >> 31) != 0, has_tips = sr.y != 0xFFFFFFFFu;
-            if (member) { nm_t += w; nroot_t += has_root ? w : 0u; if (STATS) leafp_t += (uint64_t)w * sr.w; }
-            const bool live = member && has_root && has_tips;
-            const uint32_t g = append_slot(live, &sh.n_groups);
-            if (live) {
-                hot[g] = (uint64_t)(sr.y & TILE_TIP_MASK) | ((uint64_t)(sr.z & TILE_TIP_MASK) << TILE_TIP_BITS) | ((uint64_t)w << (2 * TILE_TIP_BITS));
-                xs[g] = sr.x;
-            }
-        };
         for (uint32_t base = 0; base < n_look; base += THREADS) {
             const uint32_t j = base + tid;
             const uint32_t v = j < n_look ? wsid[j] : 0u;
-            __syncthreads();  // every window of this block is read before entries (xs[g], g <= j) overwrite the same words; the table is clear
+            __syncthreads();  // every window of this block is read before entries (xs[g], g <= j) overwrite the same words
             const uint32_t sid = v & SET_ID_MASK;
             const uint32_t kw = !sid ? 0u : (v >> 31) ? 1u : 2u;
             const uint32_t prev_sid = __shfl_up(sid, 1);
@@ -2539,21 +2521,16 @@ __global__ __launch_bounds__(THREADS) void place_tile_kernel(DbDev db, PlacePara
             const uint32_t end = later ? lane + (uint32_t)__ffsll((unsigned long long)later) - 1u : 63u;  // last lane of my run (if I am a head)
             const uint32_t ps_end = __shfl(ps, (int)end);
             const uint32_t w = head ? ps_end - (ps - kw) : 0u;
-            bool own_entry = head;
-            if (head) {
-                uint32_t pos = (sid * 2654435761u) >> 20;  // (TILE_SET_ENTRIES = 2^12)
-                for (uint32_t probes = 0; probes < 16; ++probes) {
-                    const uint32_t old = atomicCAS(&cset[pos], SET_EMPTY, sid);
-                    if (old == SET_EMPTY || old == sid) { atomicAdd(&cval[pos], w); own_entry = false; break; }
-                    pos = (pos + 1) & (TILE_SET_ENTRIES - 1);
-                }
+            uint4 sr = uint4{0u, 0xFFFFFFFFu, 0u, 0u};
+            if (head) { sr = ldx<uint4, ADDR32>(sets, sid); if (STATS) ib_t += 16; }
+            const bool has_root = (sr.z >> 31) != 0, has_tips = sr.y != 0xFFFFFFFFu;
+            if (head) { nm_t += w; nroot_t += has_root ? w : 0u; if (STATS) leafp_t += (uint64_t)w * sr.w; }
+            const bool live = head && has_root && has_tips;
+            const uint32_t g = append_slot(live, &sh.n_groups);
+            if (live) {
+                hot[g] = (uint64_t)(sr.y & TILE_TIP_MASK) | ((uint64_t)(sr.z & TILE_TIP_MASK) << TILE_TIP_BITS) | ((uint64_t)w << (2 * TILE_TIP_BITS));
+                xs[g] = sr.x;
             }
-            add_entry(own_entry, sid, w);
-        }
-        __syncthreads();
-        for (uint32_t i = tid; i < TILE_SET_ENTRIES; i += THREADS) {  // (TILE_SET_ENTRIES is a multiple of THREADS: whole wavefronts)
-            const uint32_t sid = cset[i];
-            add_entry(sid != SET_EMPTY, sid, cval[i]);
         }
         {   // |M|, |M_root| (and the statistics) over the workgroup
             const uint32_t a = wave_sum(nm_t), b = wave_sum(nroot_t);
@@ -2913,7 +2890,7 @@ PlacePlan plan_place(const DbDev& db, uint32_t n_reads, uint32_t n_cu, bool stat
         uint32_t look = want;
         const size_t lds_max = 160 * 1024 - sizeof(TileSh) - 256;
         if (tile_smem(look, bases_of(look)) > lds_max) {
-            look = (uint32_t)((lds_max - 8ull * TILE_SET_ENTRIES - 64 - 4ull * 8) / 12);
+            look = (uint32_t)((lds_max - 4ull * TILE_SET_ENTRIES - 64 - 4ull * 8) / 12);
             while (look > 64 && tile_smem(look, bases_of(look)) > lds_max) look -= 64;
         }
         look = std::min<uint32_t>(look, 32767u);  // weights are summed in 16-bit halves
