@@ -2498,6 +2498,9 @@ __global__ __launch_bounds__(THREADS) void place_tile_kernel(DbDev db, PlacePara
             if (tid == 0) spill_list[atomicAdd(spill_len, 1u)] = r;
             continue;
         }
+        // (Measured and rejected: ONE entry per distinct tip set -- every run adding its weight to an LDS table keyed by the
+        // set id, the entries then made from the table.  C5 at 0.1 scale 683 -> 653 k reads/s, at 0.3 scale 575.6 -> 583.1 ms:
+        // the runs of a read are nearly all of different sets already, the second pass only costs.)
         // ---- A2b. state entries.  Consecutive windows mostly share their tip set (a set's k-mers are the windows between
         // two mutation boundaries of a lineage): runs of equal set ids among a wavefront's 64 consecutive windows
         // become ONE entry weighted by the run, and only the run's head reads the 16-byte set record. --------------
