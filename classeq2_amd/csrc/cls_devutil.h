@@ -1,0 +1,78 @@
+// Device-side helpers shared by the kernel files (cls_kernels.hip, cls_tile.hip): wave-level primitives, scalar-unit
+// loads of tree rows, offset loads.  gfx950 / wave64 only.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "cls_device.h"
+
+namespace cls {
+namespace {
+
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__device__ __forceinline__ uint32_t uniform(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
+
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xb1, 0xf, 0xf, true);   // quad_perm:[1,0,3,2]
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4e, 0xf, 0xf, true);   // quad_perm:[2,3,0,1]
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true);  // row_shr:4
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true);  // row_shr:8
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, true);  // row_bcast:15 -> rows 1,3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, true);  // row_bcast:31 -> rows 2,3
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+
+// A DNode read through the constant address space: wave-uniform address -> s_load_dwordx8
+// (scalar cache, no vector-memory instruction).  {pre, size, first_child, n_nonleaf, id lo, id hi, split, flags}
+struct snode_t { uint32_t s[8]; };
+__device__ __forceinline__ snode_t load_node(const DNode* nodes, uint32_t row) {
+    typedef __attribute__((address_space(4))) const uint32_t as4_u32;
+    typedef __attribute__((address_space(4))) const char as4_char;
+    // (a 32-bit byte offset off the table's base: the node table stays far below 4 GiB, and the scalar load takes base + offset)
+    as4_u32* p = (as4_u32*)((as4_char*)(uintptr_t)nodes + (uint32_t)(__builtin_amdgcn_readfirstlane(row) * (uint32_t)sizeof(DNode)));
+    snode_t r;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r.s[i] = p[i];
+    return r;
+}
+
+// both children of a binary clade (consecutive rows): one 64-byte scalar load
+struct snode_pair_t { uint32_t s[16]; };
+__device__ __forceinline__ snode_pair_t load_node_pair(const DNode* nodes, uint32_t row) {
+    typedef __attribute__((address_space(4))) const uint32_t as4_u32;
+    as4_u32* p = (as4_u32*)(uintptr_t)(nodes + __builtin_amdgcn_readfirstlane(row));
+    snode_pair_t r;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) r.s[i] = p[i];
+    return r;
+}
+
+// Indexed load off a wave-uniform base.  ADDR32: the byte offset is known to fit 32 bits (arrays below
+// 4 GiB), which lets the compiler use the SGPR-base + 32-bit-VGPR-offset form instead of building a 64-bit
+// address pair per access (each pair costs an extra VGPR holding the zero high half).
+template <class T, bool ADDR32>
+__device__ __forceinline__ T ldx(const void* base, uint32_t index) {
+    if constexpr (ADDR32) return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + (uint32_t)(index * (uint32_t)sizeof(T)));
+    else return reinterpret_cast<const T*>(base)[index];
+}
+
+// 8-byte half of split record x (cls_device.h: TipRec): half 2x leads into the left part, 2x + 1 into the right one.
+// Record indices reach 2^32 - 1 (cls_db.cpp rejects more), so without ADDR32 the half index is formed in 64 bits.
+template <bool ADDR32>
+__device__ __forceinline__ uint2 ld_half(const uint32_t* half, uint32_t x, uint32_t right) {
+    if constexpr (ADDR32) return ldx<uint2, true>(half, 2 * x + right);
+    else return reinterpret_cast<const uint2*>(half)[2ull * x + right];
+}
+
+__device__ __forceinline__ uint32_t mix32(uint32_t x) {
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    return x;
+}
+
+}  // namespace
+}  // namespace cls

@@ -23,6 +23,7 @@
 #include <type_traits>
 
 #include "cls_device.h"
+#include "cls_devutil.h"
 #include "cls_kernels.h"
 #include "cls_murmur.h"
 #include "cls_sort.h"
@@ -50,14 +51,6 @@ constexpr int WAVES_PER_BLOCK = 4;
 #define FAST_MIN_WAVES_WIDE 4  // the 16-slot class keeps more state per lane: forcing 96 VGPRs on it spills 74 of them
 #endif
 constexpr uint32_t SET_EMPTY = 0xFFFFFFFFu;
-
-__device__ __forceinline__ void wave_sync() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
-__device__ __forceinline__ uint32_t uniform(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
 
 __device__ __forceinline__ uint32_t popc64(uint64_t m) { return (uint32_t)__popcll(m); }
 
@@ -940,41 +933,6 @@ __global__ __launch_bounds__(64 * WAVES) void place_block_kernel(DbDev db, Place
 // direct table), no probe loop, no per-slot branches (an absent / inactive k-mer is the state
 // {vlo = MAX, vhi = 0}), one DPP reduction per level instead of 3*SLOTS ballots, and the two children's
 // node records fetched ahead of the counting.
-__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xb1, 0xf, 0xf, true);   // quad_perm:[1,0,3,2]
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4e, 0xf, 0xf, true);   // quad_perm:[2,3,0,1]
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true);  // row_shr:4
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true);  // row_shr:8
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, true);  // row_bcast:15 -> rows 1,3
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, true);  // row_bcast:31 -> rows 2,3
-    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
-}
-
-// A DNode read through the constant address space: wave-uniform address -> s_load_dwordx8
-// (scalar cache, no vector-memory instruction).  {pre, size, first_child, n_nonleaf, id lo, id hi, split, flags}
-struct snode_t { uint32_t s[8]; };
-__device__ __forceinline__ snode_t load_node(const DNode* nodes, uint32_t row) {
-    typedef __attribute__((address_space(4))) const uint32_t as4_u32;
-    typedef __attribute__((address_space(4))) const char as4_char;
-    // (a 32-bit byte offset off the table's base: the node table stays far below 4 GiB, and the scalar load takes base + offset)
-    as4_u32* p = (as4_u32*)((as4_char*)(uintptr_t)nodes + (uint32_t)(__builtin_amdgcn_readfirstlane(row) * (uint32_t)sizeof(DNode)));
-    snode_t r;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) r.s[i] = p[i];
-    return r;
-}
-
-// both children of a binary clade (consecutive rows): one 64-byte scalar load
-struct snode_pair_t { uint32_t s[16]; };
-__device__ __forceinline__ snode_pair_t load_node_pair(const DNode* nodes, uint32_t row) {
-    typedef __attribute__((address_space(4))) const uint32_t as4_u32;
-    as4_u32* p = (as4_u32*)(uintptr_t)(nodes + __builtin_amdgcn_readfirstlane(row));
-    snode_pair_t r;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) r.s[i] = p[i];
-    return r;
-}
-
 // Where the third, fourth and fifth child of a clade start (DbDev.kids): 16 bytes through the scalar unit.
 struct skids_t { uint32_t s[4]; };
 __device__ __forceinline__ skids_t load_kids(const uint32_t* kids, uint32_t row) {
@@ -984,15 +942,6 @@ __device__ __forceinline__ skids_t load_kids(const uint32_t* kids, uint32_t row)
 #pragma unroll
     for (int i = 0; i < 4; ++i) r.s[i] = p[i];
     return r;
-}
-
-// Indexed load off a wave-uniform base.  ADDR32: the byte offset is known to fit 32 bits (arrays below
-// 4 GiB), which lets the compiler use the SGPR-base + 32-bit-VGPR-offset form instead of building a 64-bit
-// address pair per access (each pair costs an extra VGPR holding the zero high half).
-template <class T, bool ADDR32>
-__device__ __forceinline__ T ldx(const void* base, uint32_t index) {
-    if constexpr (ADDR32) return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + (uint32_t)(index * (uint32_t)sizeof(T)));
-    else return reinterpret_cast<const T*>(base)[index];
 }
 
 struct FastCtx {
@@ -1234,7 +1183,7 @@ __device__ __forceinline__ void descend_groups(const DbDev& db, const PlaceParam
             const uint32_t z = (uint32_t)__ffs((int)up) - 1u;
             v = bound + z; xx = up >> (z & 31u);
         } else {
-            const uint2 t = ldx<uint2, ADDR32>(half, 2 * xx + 1);
+            const uint2 t = ld_half<ADDR32>(half, xx, 1u);
             if (STATS) ib += 8;
             v = t.x & ~MASK_HALF; xx = t.y;
             if (MASKS) bits = (t.x & MASK_HALF) != 0u;
@@ -1381,7 +1330,7 @@ __device__ __forceinline__ void descend_groups(const DbDev& db, const PlaceParam
                     if (vh >= c_end) {                // ... and tips beyond it: keep the part inside
                         if (MASKS && bits) { xx &= (1u << ((c_end - v) & 31u)) - 1u; vh = v + 31u - (uint32_t)__clz((int)xx); }
                         else {
-                            const uint2 t = ldx<uint2, ADDR32>(half, 2 * xx);
+                            const uint2 t = ld_half<ADDR32>(half, xx, 0u);
                             if (STATS) ib += 8;
                             vh = t.x & ~MASK_HALF; xx = t.y;
                             if (MASKS) bits = (t.x & MASK_HALF) != 0u;
@@ -1484,7 +1433,7 @@ __device__ __forceinline__ void descend_groups(const DbDev& db, const PlaceParam
                 if (STATS) ib += rd & 8u;
             };
             auto request = [&](uint32_t x_, uint32_t rd) -> uint2 {
-                return ldx<uint2, ADDR32>(half, (2 * x_ + (RIGHT ? 1u : 0u)) & rd);  // (record 0: the dummy)
+                return ld_half<ADDR32>(half, x_ & rd, (RIGHT ? 1u : 0u) & rd);  // (record 0: the dummy)
             };
             auto finish = [&](uint32_t& lo_, uint32_t& hi_, uint32_t& x_, uint32_t& w_, uint32_t strm, uint32_t rd, uint32_t aux, uint2 t) {
                 uint32_t end = t.x, xn = t.y;  // what the read gave: the new last (left) / first (right) tip, the part's split or bits
@@ -1768,10 +1717,6 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, SLOTS > 5 ? FAST_MIN_WAVES_WI
 //   key_mode 0: {median set id >> block_shift, 16-bit MinHash of the specific k-mers}: leaf neighbourhood first
 //   key_mode 1: {20-bit MinHash of ALL present k-mers, median set id}: locus first
 // Reads the fast kernel will not place (too short / too long / bad characters) get the last key.
-__device__ __forceinline__ uint32_t mix32(uint32_t x) {
-    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
-    return x;
-}
 __device__ __forceinline__ uint64_t make_order_key(uint32_t key_mode, uint32_t median, uint32_t mh_spec, uint32_t mh_all, uint32_t block_shift, uint32_t set_bits) {
     if (key_mode == 1) return ((uint64_t)(mh_all >> 12) << set_bits) | median;
     return ((uint64_t)(median >> block_shift) << 16) | (mh_spec >> 16);
@@ -1991,8 +1936,6 @@ struct LongSh {
     uint32_t cpre[LONG_LDS_ARITY + 1];  // where the current clade's non-LEAF children start (+ the end of the last)
     uint32_t cnt_l[LONG_LDS_ARITY], only_l[LONG_LDS_ARITY];  // per-child counters of clades with at most that many
 };
-
-__device__ __forceinline__ uint32_t wave_sum(uint32_t v);
 
 // position of this thread's element in a list that all threads of the workgroup append to (wave-aggregated)
 __device__ __forceinline__ uint32_t append_slot(bool keep, uint32_t* counter) {
@@ -2641,7 +2584,7 @@ __global__ __launch_bounds__(THREADS) void place_tile_kernel(DbDev db, PlacePara
                 }
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    t[i] = ldx<uint2, ADDR32>(half, str[i] ? 2 * xv[i] + (right ? 1u : 0u) : 0u);  // (record 0: the dummy)
+                    t[i] = ld_half<ADDR32>(half, str[i] ? xv[i] : 0u, (str[i] && right) ? 1u : 0u);  // (record 0: the dummy)
                     if (STATS && str[i]) ib += 8;
                 }
 #pragma unroll
@@ -2819,6 +2762,7 @@ size_t blk_smem(const DbDev& db) {
 std::string dominant_kernel_name(const DbDev& db, bool stats, const PlacePlan* plan) {
     const std::string sl = std::to_string(CLS_SLOTS[0]) + ", " + std::to_string(set_bits_of(db, 0)) + ", " + (stats ? "true" : "false");
     auto b = [](bool v) { return std::string(v ? "true" : "false"); };
+    if (plan && plan->grid_tile && plan->tile_slots) return regtile_kernel_name(db, stats, plan->tile_threads, plan->tile_slots);
     if (plan && plan->grid_tile)  // a launch provisioned for long reads: the LDS-tiled kernel is the one that is timed
         return "place_tile_kernel<" + std::to_string(plan->tile_threads) + ", " + b(db.canonical != 0) + ", " + b(stats) + ", " + b(db.addr32 != 0) + ">";
     if (use_fast(db))
@@ -2886,7 +2830,11 @@ PlacePlan plan_place(const DbDev& db, uint32_t n_reads, uint32_t n_cu, bool stat
     w += child_words;
     w += w & 1;
     // LDS-tiled long-read class (binary FMT_SPLIT index with a direct table): as many lookups per read as 160 KB of LDS hold
-    if (long_cap > MAX_READ_KMERS && n_long && use_tile(db)) {
+    if (long_cap > MAX_READ_KMERS && n_long && regtile_usable(db)) {  // the register-tiled kernel (cls_tile.hip)
+        const RegTilePlan rt = regtile_plan(db, long_cap, n_long, n_cu, stats);
+        p.grid_tile = rt.grid; p.tile_threads = rt.threads; p.tile_slots = rt.slots; p.tile_lookups = rt.lookups;
+        p.tile_bases = rt.bases; p.tile_smem = rt.smem; p.tile_cap_kmers = rt.cap_kmers;
+    } else if (long_cap > MAX_READ_KMERS && n_long && use_tile(db)) {
         const bool canon = db.canonical != 0;
         const uint32_t want = canon ? long_cap / 2 : long_cap;  // lookups of the longest read (canonical: one per window)
         auto bases_of = [&](uint32_t look) { return (canon ? look : look / 2) + db.k; };
@@ -3060,6 +3008,10 @@ hipError_t launch_place(const DbDev& db, const PlaceParams& prm, const PlacePlan
     if (plan.grid_tile) {  // class 3: long reads, every state in LDS; reads it cannot hold are appended to class 4's list
         if (hipGetLastError() != hipSuccess) return hipErrorLaunchFailure;
         if (ev_start) (void)hipEventRecord(ev_start, stream);
+        if (plan.tile_slots) {
+            const RegTilePlan rt{plan.tile_threads, plan.tile_slots, plan.tile_lookups, plan.tile_bases, plan.tile_cap_kmers, plan.grid_tile, plan.tile_smem};
+            regtile_launch(db, prm, rt, st, d_bases, d_offsets, lists[3], counts + 3, d_out, d_stats, lists[4], counts + 4, stream);
+        } else {
 #define CLS_LAUNCH_TILE(TH, CN, ST, A32)                                                                                          \
     do {                                                                                                                          \
         auto kfn = place_tile_kernel<TH, CN, ST, A32>;                                                                            \
@@ -3075,6 +3027,7 @@ hipError_t launch_place(const DbDev& db, const PlaceParams& prm, const PlacePlan
 #undef CLS_LAUNCH_TILE2
 #undef CLS_LAUNCH_TILE3
 #undef CLS_LAUNCH_TILE
+        }
         if (ev_stop) (void)hipEventRecord(ev_stop, stream);
     }
     if (plan.grid_long) {  // class 4: reads beyond what the LDS holds (and every long read of the other index shapes): state in the workspace

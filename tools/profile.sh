@@ -15,7 +15,7 @@ timeout -k 10 400 rocprofv3 --pmc FETCH_SIZE -d "$OUT/pmc_fetch" -o fetch --outp
 timeout -k 10 400 rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum -d "$OUT/pmc_tcc" -o tcc --output-format csv -- $BENCH > /dev/null 2> "$OUT/pmc_tcc.err"
 cd - > /dev/null
 timeout -k 10 300 $BENCH > "$OUT/bench.json" 2> "$OUT/bench.err"
-python3 tools/pmc_summary.py "$OUT" > "$OUT/pmc_summary.json"
+python3 tools/pmc_summary.py "$OUT" --command "rocprofv3 --pmc FETCH_SIZE | --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum (separate passes) -- $BENCH" > "$OUT/pmc_summary.json"
 python3 - "$OUT" <<'PY'
 import csv, glob, re, sys
 src = glob.glob(sys.argv[1] + "/kt/*kernel_stats.csv")[0]

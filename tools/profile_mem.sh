@@ -11,7 +11,7 @@ cd /tmp
 timeout -k 10 600 rocprofv3 --pmc FETCH_SIZE TCP_TCC_READ_REQ_sum -d "$OUT/mem_$CFG/a" -o a --output-format csv -- $BENCH > /dev/null 2> "$OUT/mem_$CFG/a.err"
 timeout -k 10 600 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum -d "$OUT/mem_$CFG/b" -o b --output-format csv -- $BENCH > /dev/null 2> "$OUT/mem_$CFG/b.err"
 cd - > /dev/null
-python3 tools/pmc_summary.py "$OUT/mem_$CFG" > "$OUT/mem_$CFG.json"
+python3 tools/pmc_summary.py "$OUT/mem_$CFG" --command "rocprofv3 --pmc FETCH_SIZE TCP_TCC_READ_REQ_sum | --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum (separate passes) -- $BENCH" > "$OUT/mem_$CFG.json"
 find "$OUT/mem_$CFG" -name "*counter_collection.csv" -delete
 find "$OUT/mem_$CFG" -name "*agent_info.csv" -delete
 python3 - "$OUT/mem_$CFG.json" <<'PY'

@@ -11,7 +11,7 @@ cd /tmp
 timeout -k 10 600 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INSTS_SMEM SQ_WAVES -d "$OUT/sq_$CFG/a" -o a --output-format csv -- $BENCH > /dev/null 2> "$OUT/sq_$CFG/a.err"
 timeout -k 10 600 rocprofv3 --pmc SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_INST_CYCLES_SALU SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_ANY -d "$OUT/sq_$CFG/b" -o b --output-format csv -- $BENCH > /dev/null 2> "$OUT/sq_$CFG/b.err"
 cd - > /dev/null
-python3 tools/pmc_summary.py "$OUT/sq_$CFG" > "$OUT/sq_$CFG.json"
+python3 tools/pmc_summary.py "$OUT/sq_$CFG" --command "rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INSTS_SMEM SQ_WAVES | --pmc SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_INST_CYCLES_SALU SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_ANY (separate passes) -- $BENCH" > "$OUT/sq_$CFG.json"
 find "$OUT/sq_$CFG" -name "*counter_collection.csv" -delete
 find "$OUT/sq_$CFG" -name "*agent_info.csv" -delete
 python3 - "$OUT/sq_$CFG.json" <<'PY'
