@@ -14,7 +14,9 @@ the single gather of the 24-byte placement records to rank 0 over RCCL:
     rank -> "strong" scaling.
 Other --config values are the shapes SURVEY.md 8 / VERDICT name: C2 (1k-leaf,
 k=8), C5 (50k-leaf deep tree, 10 kb reads, k=15), C3s12 / C3s35 (the
-support-collapsed 10k-leaf tree at k=12 and at the reference's default k=35).
+support-collapsed 10k-leaf tree at k=12 and at the reference's default k=35), G35
+(the reference's documented workload: ~1.9 kb gyrB queries, ~590-node
+support-collapsed tree, k=35, m=4).
 
 Rank 0 prints ONE JSON line; DESIGN.md "Measurement" says how `roofline`,
 `host_window` and `cpu_baseline` are obtained.
@@ -157,12 +159,62 @@ def host_window(db, bases, offsets, n, reps=5):
     return res, last
 
 
+def e2e_window(db, synth, cfg, bases, n):
+    """SURVEY.md 8(d) window (ii) = the reference's UCPLACE0001 -> 0002 (mod.rs:64-67, 264-267): query FASTA file in,
+    result file out (parse + placement + serialisation + write), database load excluded.  One warm-up, then one timed
+    run per output format; `window_s` is what cls_place_sequences measures inside, `wall_s` the call."""
+    import tempfile
+
+    from classeq2_amd import _abi, engine
+
+    kinds = ["ROOT", "NODE", "LEAF"]
+    nodes = synth.flat.nodes
+    sys.setrecursionlimit(1_000_000)
+
+    def clade(r):
+        d = {"id": int(nodes[r]["id"]), "parent": None if int(nodes[r]["parent"]) == _abi.NO_PARENT else int(nodes[r]["parent"]),
+             "kind": kinds[int(nodes[r]["kind"])]}
+        if nodes[r]["kind"] == 2:
+            d["name"] = f"leaf_{int(nodes[r]['id'])}"
+        else:
+            d["support"] = 100.0
+        d["length"] = 0.01
+        if nodes[r]["has_children"]:
+            d["children"] = [clade(int(nodes[r]["first_child"]) + i) for i in range(int(nodes[r]["n_children"]))]
+        return d
+
+    tmp = tempfile.mkdtemp(prefix="cls_e2e_")
+    with open(os.path.join(tmp, "tree.json"), "w") as f:
+        json.dump(clade(0), f)
+    tree = engine.Tree(os.path.join(tmp, "tree.json"))
+    rows = bases[: n * cfg["read_len"]].reshape(n, cfg["read_len"])
+    query = os.path.join(tmp, "q.fasta")
+    with open(query, "wb") as f:
+        for lo in range(0, n, 100_000):
+            f.write(b"".join(b">r%d\n" % (lo + i) + bytes(row) + b"\n" for i, row in enumerate(rows[lo:lo + 100_000])))
+    out = {"what": "query FASTA file -> result file (cls_place_sequences: parse + placement + serialisation + write; database load "
+                   "excluded), one warm-up then one timed run per format", "reads": n, "query_bytes": os.path.getsize(query)}
+    for fmt, name in ((engine.FORMAT_JSONL, "jsonl"), (engine.FORMAT_YAML, "yaml")):
+        engine.place_sequences(db, tree, query, os.path.join(tmp, "warm"), overwrite=True, fmt=fmt)
+        t0 = time.perf_counter()
+        got, sec = engine.place_sequences(db, tree, query, os.path.join(tmp, "res"), overwrite=True, fmt=fmt)
+        wall = time.perf_counter() - t0
+        out[name] = {"window_s": round(sec, 4), "wall_s": round(wall, 4), "placements_per_s": round(got / sec),
+                     "result_bytes": os.path.getsize(os.path.join(tmp, "res." + name))}
+        assert got == n
+    import shutil
+    shutil.rmtree(tmp, ignore_errors=True)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--config", default="C3", choices=["C2", "C3", "C4", "C5", "C3s12", "C3s35"])
+    ap.add_argument("--config", default="C3", choices=["C2", "C3", "C4", "C5", "C3s12", "C3s35", "G35"])
+    ap.add_argument("--e2e", action="store_true", help="add SURVEY.md 8(d) window (ii): query FASTA file -> result file (cls_place_sequences, "
+                    "mod.rs:64-67 / 264-267), JSONL and YAML, on this config's reads")
     ap.add_argument("--reads", type=int, default=0, help="reads per GPU (default: the config's; C4: total reads of the stream)")
     ap.add_argument("--scale", type=float, default=1.0, help="C5 only: fraction of the 50k leaves / 1M reads to run")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -214,20 +266,58 @@ def main():
         total_reads = per_gpu * world
         first = rank * per_gpu
     cfg["n_reads"] = per_gpu
-    threads = max(1, (os.cpu_count() or 8) // max(1, min(world, 8)))
+    if args.config == "G35":
+        engine.set_tuning("time_class", 2)  # 1.9 kb reads: the workgroup-per-read kernel is the one to time and name
     t0 = time.time()
-    synth = SynthDb(cfg["n_leaves"], cfg["ref_len"], cfg["k_size"], cfg["m_size"], deep=cfg["deep"],
-                    max_depth=cfg["max_depth"], collapse_prob=cfg.get("collapse_prob", 0.0), threads=threads,
-                    tips_only=cfg.get("tips_only", False))
+    synth = None
+    if world == 1 or rank == 0:
+        # N > 1: ONE rank generates the synthetic index and every rank's shard of the read stream with all the host's
+        # threads and leaves them in shared memory; the others map them (8 generators side by side took minutes on C5)
+        synth = SynthDb(cfg["n_leaves"], cfg["ref_len"], cfg["k_size"], cfg["m_size"], deep=cfg["deep"],
+                        max_depth=cfg["max_depth"], collapse_prob=cfg.get("collapse_prob", 0.0), threads=os.cpu_count() or 8,
+                        tips_only=cfg.get("tips_only", False))
+        flat = synth.flat
+    share = None
+    if world > 1:
+        share = os.path.join("/dev/shm" if os.path.isdir("/dev/shm") else "/tmp", f"cls_bench_{os.environ.get('MASTER_PORT', '0')}_{args.config}")
+        fields = ("nodes", "bucket_key", "bucket_kmer_off", "kmer_hash", "kmer_node_off", "node_ids")
+        if rank == 0:
+            os.makedirs(share, exist_ok=True)
+            for name in fields:
+                np.save(os.path.join(share, name + ".npy"), getattr(flat, name))
+            for rk in range(world):
+                f_rk = rk * per_gpu
+                m_rk = max(0, min(per_gpu, total_reads - f_rk)) if strong else per_gpu
+                b_rk, o_rk, _ = synth.reads(max(m_rk, 1), cfg["read_len"], seed=3, first=f_rk)
+                np.save(os.path.join(share, f"bases_{rk}.npy"), b_rk)
+                np.save(os.path.join(share, f"offsets_{rk}.npy"), o_rk)
+        dist.barrier()
+        if rank != 0:
+            from classeq2_amd.flatdb import FlatDb
+            arrs = {name: np.load(os.path.join(share, name + ".npy"), mmap_mode="r") for name in fields}
+            flat = FlatDb(k_size=cfg["k_size"], m_size=cfg["m_size"], leaves_only=bool(cfg.get("tips_only", False)), **arrs)
     gen_s = time.time() - t0
     t0 = time.time()
-    db = engine.PlacementDb(synth.flat, device=local_rank)
+    db = engine.PlacementDb(flat, device=local_rank)
     create_s = time.time() - t0
     if cfg["read_len"] > 4096:
         db.set_max_read_len(cfg["read_len"])
     # this rank's shard of the global read stream (seed 3); every rank allocates per_gpu records so that the
     # gather has one shape (the last shard of a strong-scaling split may be shorter: its tail stays zero)
-    bases, offsets, _ = synth.reads(max(mine, 1), cfg["read_len"], seed=3, first=first)
+    if world > 1:
+        bases = np.load(os.path.join(share, f"bases_{rank}.npy"))
+        offsets = np.load(os.path.join(share, f"offsets_{rank}.npy"))
+        dist.barrier()  # everyone has read its files
+        if rank == 0:
+            import shutil
+            shutil.rmtree(share, ignore_errors=True)
+    else:
+        bases, offsets, _ = synth.reads(max(mine, 1), cfg["read_len"], seed=3, first=first)
+    setup = torch.tensor([gen_s, create_s], dtype=torch.float64)
+    if world > 1:
+        setup = setup.to("cpu" if rehearsal else dev)
+        dist.all_reduce(setup, op=dist.ReduceOp.MAX)  # the slowest rank's setup
+    gen_s, create_s = float(setup[0]), float(setup[1])
     d_bases = torch.from_numpy(bases).to(dev)
     d_off = torch.from_numpy(offsets.view(np.int64)).to(dev)
     d_outs = [torch.zeros(per_gpu * 24, dtype=torch.uint8, device=dev) for _ in range(2)]  # double-buffered records
@@ -316,7 +406,8 @@ def main():
                   "C2": "query placements/sec, 1k-leaf tree, 150 bp reads",
                   "C5": "query placements/sec, 50k-leaf deep tree, 10 kb reads",
                   "C3s12": "query placements/sec, support-collapsed 10k-leaf tree, 150 bp reads",
-                  "C3s35": "query placements/sec, support-collapsed 10k-leaf tree, 150 bp reads, k=35"}[args.config]
+                  "C3s35": "query placements/sec, support-collapsed 10k-leaf tree, 150 bp reads, k=35",
+                  "G35": "query placements/sec, 300-leaf support-collapsed tree, 1.9 kb reads, k=35 (the reference's documented workload)"}[args.config]
         line = {
             "metric": metric,
             "value": total / elapsed,
@@ -344,7 +435,8 @@ def main():
                           "hbm_bytes": int(db.info.hbm_bytes), "input": "tips only" if cfg.get("tips_only") else "explicit node sets"},
                 "status_counts": {_abi.STATUS_NAMES[i]: int(c) for i, c in enumerate(counts) if c},
                 "mean_levels": float(ref_out["levels"][:mine].mean()) if mine else 0.0,
-                "setup_s": {"generate": round(gen_s, 1), "db_create": round(create_s, 1)},
+                "setup_s": {"generate": round(gen_s, 1), "db_create": round(create_s, 1),
+                            "what": "slowest rank; N > 1: rank 0 generates index + read shards once, the others map them from shared memory"},
                 "scratch_slots": int(slots),
             },
             "roofline": {
@@ -391,6 +483,8 @@ def main():
             for f in ("status", "one", "rest", "levels", "clade_id"):
                 assert (host_recs[f] == ref_out[f][:mine]).all(), "host-buffer entry disagrees with the device-buffer entry"
             line["host_window"] = hw
+        if args.e2e and world == 1 and mine:
+            line["e2e"] = e2e_window(db, synth, cfg, bases, mine)
         if not args.no_cpu_baseline and world == 1:  # rank 0 at N=1 only
             cb, oracle_recs = cpu_baseline(synth, cfg, first)
             n_chk = min(len(oracle_recs), mine)

@@ -51,6 +51,7 @@ struct Workspace {
 struct TimedPair {
     hipEvent_t t0 = nullptr, t1 = nullptr;
     bool pending = false;                   // recorded, not yet folded into the handle's accumulators
+    bool in_use = false;                    // handed to a launch that has not recorded it yet (set and cleared under ws_mu)
 };
 constexpr size_t MAX_WS_SLOTS = 8;          // scratch slots per handle; beyond it a caller waits for the oldest launch
 constexpr size_t MAX_TIMED_PAIRS = 256;     // launches in flight whose kernel time is still to be harvested
@@ -118,7 +119,7 @@ namespace {
 struct Knob { const char* name; int cls::Tuning::*field; };
 const Knob KNOBS[] = {
     {"no_fast", &cls::Tuning::no_fast}, {"no_order", &cls::Tuning::no_order}, {"force_list", &cls::Tuning::force_list},
-    {"no_mask_halves", &cls::Tuning::no_mask_halves}, {"no_fat_direct", &cls::Tuning::no_fat_direct}, {"no_tile", &cls::Tuning::no_tile}, {"tile_pass_codes", &cls::Tuning::tile_pass_codes}, {"tile_v1", &cls::Tuning::tile_v1}, {"tile_blocks_per_cu", &cls::Tuning::tile_blocks_per_cu}, {"blocks_per_cu", &cls::Tuning::blocks_per_cu}, {"key_blocks_per_cu", &cls::Tuning::key_blocks_per_cu},
+    {"no_mask_halves", &cls::Tuning::no_mask_halves}, {"no_fat_direct", &cls::Tuning::no_fat_direct}, {"no_tile", &cls::Tuning::no_tile}, {"tile_pass_codes", &cls::Tuning::tile_pass_codes}, {"time_class", &cls::Tuning::time_class}, {"blocks_per_cu", &cls::Tuning::blocks_per_cu}, {"key_blocks_per_cu", &cls::Tuning::key_blocks_per_cu},
     {"long_blocks_per_cu", &cls::Tuning::long_blocks_per_cu}, {"order_mode", &cls::Tuning::order_mode},
     {"order_windows", &cls::Tuning::order_windows}, {"order_both_strands", &cls::Tuning::order_both_strands},
     {"order_block_shift", &cls::Tuning::order_block_shift}, {"order_sample_shift", &cls::Tuning::order_sample_shift},
@@ -314,11 +315,12 @@ static void harvest(cls_db* db, bool wait) {
 static size_t acquire_timed(cls_db* db) {
     harvest(db, false);
     for (size_t i = 0; i < db->timed.size(); ++i)
-        if (!db->timed[i].pending && db->timed[i].t0) { db->timed[i].pending = false; return i; }
+        if (!db->timed[i].pending && !db->timed[i].in_use && db->timed[i].t0) { db->timed[i].in_use = true; return i; }
     if (db->timed.size() >= MAX_TIMED_PAIRS) return SIZE_MAX;
     TimedPair t;
     if (hipEventCreate(&t.t0) != hipSuccess) return SIZE_MAX;
     if (hipEventCreate(&t.t1) != hipSuccess) { (void)hipEventDestroy(t.t0); return SIZE_MAX; }
+    t.in_use = true;
     db->timed.push_back(t);
     return db->timed.size() - 1;
 }
@@ -423,7 +425,7 @@ static int place_device(cls_db* db, const void* d_bases, const void* d_offsets, 
     bool record_failed = false;
     {
         std::lock_guard<std::mutex> g(db->ws_mu);
-        if (tp != SIZE_MAX) db->timed[tp].pending = (e == hipSuccess);
+        if (tp != SIZE_MAX) { db->timed[tp].pending = (e == hipSuccess); db->timed[tp].in_use = false; }
         // (another thread may have grown the vector meanwhile; slots are only erased while idle, never this one)
         for (size_t i = 0; i < db->ws.size(); ++i)
             if (db->ws[i].ptr == use.ptr) { slot = i; break; }

@@ -30,18 +30,17 @@ struct PlacePlan {
     uint32_t tile_bases;       // bases per read its LDS holds
     uint32_t tile_cap_kmers;   // the same as a k-mer count (classification bound)
     size_t tile_smem;          // dynamic LDS of that kernel
-    uint32_t tile_slots;       // > 0: the register-tiled kernel (cls_tile.hip) with that many entries per thread; 0: the LDS-resident one
     uint64_t ws_bytes;         // device scratch the launch needs
 };
-// Register-tiled long-read kernel (cls_tile.hip): binary FMT_SPLIT index with a direct table.
-struct RegTilePlan { uint32_t threads, slots, lookups, bases, cap_kmers, grid; size_t smem; };
-bool regtile_usable(const DbDev& db);
-RegTilePlan regtile_plan(const DbDev& db, uint32_t want_kmers, uint32_t n_long, uint32_t n_cu, bool stats);
-std::string regtile_kernel_name(const DbDev& db, bool stats, uint32_t threads, uint32_t slots);
+// LDS-tiled long-read kernel (cls_tile.hip): binary FMT_SPLIT index with a direct table.
+struct TilePlan { uint32_t threads, lookups, bases, cap_kmers, grid; size_t smem; };
+bool tile_usable(const DbDev& db);
+TilePlan tile_plan(const DbDev& db, uint32_t want_kmers, uint32_t n_long, uint32_t n_cu);
+std::string tile_kernel_name(const DbDev& db, bool stats, uint32_t threads);
 // reads of `list` (device, *list_len of them) -> records; reads its code set cannot hold are appended to `spill_list`
-void regtile_launch(const DbDev& db, const PlaceParams& prm, const RegTilePlan& p, bool stats, const uint8_t* d_bases, const uint64_t* d_offsets,
-                    const uint32_t* list, const uint32_t* list_len, cls_placement* d_out, cls_query_stats* d_stats, uint32_t* spill_list,
-                    uint32_t* spill_len, hipStream_t stream);
+void tile_launch(const DbDev& db, const PlaceParams& prm, const TilePlan& p, bool stats, const uint8_t* d_bases, const uint64_t* d_offsets,
+                 const uint32_t* list, const uint32_t* list_len, cls_placement* d_out, cls_query_stats* d_stats, uint32_t* spill_list,
+                 uint32_t* spill_len, hipStream_t stream);
 // `long_cap`: k-mer capacity wanted for reads beyond MAX_READ_KMERS (0 = refuse them), `n_long`: how many
 // such reads the batch may hold (bounds the number of workspace slices).
 PlacePlan plan_place(const DbDev& db, uint32_t n_reads, uint32_t n_cu, bool stats, uint32_t long_cap, uint32_t n_long);

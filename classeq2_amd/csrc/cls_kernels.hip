@@ -2301,313 +2301,6 @@ __global__ __launch_bounds__(LONG_THREADS) void place_long_kernel(DbDev db, Plac
     }
 }
 
-// ---- long reads, LDS-tiled: one WORKGROUP per read, every per-k-mer state in LDS -----------------------------
-// BASELINE config 5 (10 kb reads, k = 15, deep tree).  For FMT_SPLIT indexes with a direct table on binary trees:
-//   front   the read packed 2 bits per base in LDS; per window (canonical index: one lookup for both strands) the
-//           2-bit code -> direct table -> tip-set id; distinct k-mers through an LDS set of codes that is filled in
-//           PASSES over hash partitions of the codes (a 16 KB set serves a read of any length); the first k-mer
-//           with a code reads its 16-byte set record and, if the set has tips, appends {first tip, last tip,
-//           weight | split} to the read's state arrays in LDS (12 bytes per distinct matching k-mer);
-//   descent every thread owns the same state entries at every level: count pass (3 compares per entry, one DPP
-//           reduction per wave, two LDS atomics per wave), ONE barrier, the decision (node records through the
-//           scalar unit), narrow pass (one 8-byte split half per entry with tips on both sides).  No state ever
-//           leaves the CU; per level the only global reads are the chosen child's node record and the split halves.
-// A read whose codes overflow a partition of the set (only an adversarial read can) is handed to the workspace
-// kernel below through the spill list: no input can make the probing loop spin.
-constexpr uint32_t TILE_SET_ENTRIES = 4096;      // LDS set of codes per pass (16 KB)
-constexpr uint32_t TILE_PASS_CODES = 1536;       // lookups per pass: load <= 0.375 for hash-partitioned distinct codes
-constexpr uint32_t TILE_TIP_BITS = 24;           // pre-order indices the packed state holds
-constexpr uint32_t TILE_TIP_MASK = (1u << TILE_TIP_BITS) - 1;
-struct TileSh {
-    uint32_t cnt[3][2];      // rotating per-level counters {in a | in b << 16, in both}
-    uint32_t n_groups;
-    uint32_t n_m, n_root;
-    uint32_t overflow;
-    uint32_t ib;
-    unsigned long long leafp;
-};
-__host__ __device__ inline uint32_t tile_packed_words(uint32_t max_bases) { return ((max_bases + 15) / 16 + 2 + 3) & ~3u; }
-// dynamic LDS of the tile kernel for reads of up to `max_lookups` table lookups and `max_bases` bases
-__host__ __device__ inline size_t tile_smem(uint32_t max_lookups, uint32_t max_bases) {
-    return 4ull * tile_packed_words(max_bases) + 4ull * TILE_SET_ENTRIES + 8ull * max_lookups + 4ull * max_lookups + 16;
-}
-
-template <int THREADS, bool CANON, bool STATS, bool ADDR32>
-__global__ __launch_bounds__(THREADS) void place_tile_kernel(DbDev db, PlaceParams prm, const uint8_t* __restrict__ bases,
-                                                             const uint64_t* __restrict__ offsets, const uint32_t* __restrict__ list,
-                                                             const uint32_t* __restrict__ list_len, cls_placement* __restrict__ out,
-                                                             cls_query_stats* __restrict__ stats, uint32_t max_lookups, uint32_t max_bases,
-                                                             uint32_t pass_codes, uint32_t* __restrict__ spill_list, uint32_t* __restrict__ spill_len) {
-    extern __shared__ __align__(16) uint8_t smem[];
-    __shared__ TileSh sh;
-    uint32_t* const packed = reinterpret_cast<uint32_t*>(smem);
-    uint32_t* const cset = packed + tile_packed_words(max_bases);
-    uint64_t* const hot = reinterpret_cast<uint64_t*>(cset + TILE_SET_ENTRIES);   // {first tip : 24, last tip : 24, weight : 16}
-    uint32_t* const xs = reinterpret_cast<uint32_t*>(hot + max_lookups);           // root split of the entry's set
-    uint32_t* const wsid = xs;  // front only: per window its tip-set id | palindrome << 31 if it is the first with its code, else 0
-    const uint32_t tid = threadIdx.x, lane = tid & 63;
-    const uint32_t k = db.k;
-    const uint32_t kmask = (1u << (2 * k)) - 1u;  // k <= 15
-    const uint32_t* __restrict__ direct = db.direct;
-    const uint4* __restrict__ sets = reinterpret_cast<const uint4*>(db.sets);
-    const uint32_t* __restrict__ half = db.postings;  // split record x = 8-byte halves 2x (left part), 2x + 1 (right part)
-    const bool rm = prm.remove_intersection != 0;
-    const uint32_t n_list = *list_len;
-    for (uint32_t li = blockIdx.x; li < n_list; li += gridDim.x) {
-        __syncthreads();  // the previous read's use of the LDS is over
-        const uint32_t r = list[li];
-        const uint64_t b0 = offsets[r], L64 = offsets[r + 1] - b0;
-        auto put_stats = [&](uint32_t nk_, uint32_t nm, uint32_t nr, uint64_t lp, uint32_t ibytes) {
-            if (STATS && stats && tid == 0) {
-                uint64_t* s = reinterpret_cast<uint64_t*>(stats + r);
-                s[0] = (uint64_t)nk_ | ((uint64_t)nm << 32);
-                s[1] = (uint64_t)nr | ((uint64_t)ibytes << 32);
-                s[2] = lp;
-            }
-        };
-        auto record = [&](uint32_t status, int32_t one, int32_t rest, uint32_t levels, uint64_t clade) {
-            if (tid == 0) {
-                uint64_t* o = reinterpret_cast<uint64_t*>(out + r);
-                o[0] = (uint64_t)(status & 0xFF) | ((uint64_t)(uint32_t)one << 32);
-                o[1] = (uint64_t)(uint32_t)rest | ((uint64_t)levels << 32);
-                o[2] = clade;
-            }
-        };
-        // (classification keeps L >= k and the lookups within max_lookups; checked all the same: never trust a list)
-        if (L64 < k || L64 > max_bases) { put_stats(0, 0, 0, 0, 0); record(L64 < k ? CLS_ERR_TOO_FEW_KMERS : CLS_ERR_READ_TOO_LONG, 0, 0, 0, 0); continue; }
-        const uint32_t L = (uint32_t)L64, nf = L - k + 1, nk = 2 * nf;
-        const uint32_t n_look = CANON ? nf : nk;
-        if (n_look > max_lookups) { put_stats(nk, 0, 0, 0, 0); record(CLS_ERR_READ_TOO_LONG, 0, 0, 0, 0); continue; }
-        // ---- A1. load, validate (reverse_complement panics on non-ACGT, kmers_map.rs:440), pack 2 bits per base ----
-        bool bad = false;
-        const uint32_t n_words = (L + 15) >> 4;
-        for (uint32_t w = tid; w < n_words + 2; w += THREADS) {
-            uint32_t acc = 0;
-            for (uint32_t q = 0; q < 16; ++q) {
-                const uint32_t i = 16 * w + q;
-                if (i >= L) break;
-                uint8_t c = bases[b0 + i];
-                if (c >= 'a' && c <= 'z') c -= 32;
-                bad |= !(c == 'A' || c == 'C' || c == 'G' || c == 'T');
-                acc |= (uint32_t)((c >> 1) & 3u) << (2 * q);  // A0 C1 T2 G3
-            }
-            packed[w] = acc;
-        }
-        if (tid == 0) { sh.n_groups = 0; sh.n_m = 0; sh.n_root = 0; sh.overflow = 0; sh.ib = 0; sh.leafp = 0; }
-        if (tid < 6) (&sh.cnt[0][0])[tid] = 0;
-        if (__syncthreads_or(bad ? 1 : 0)) { put_stats(0, 0, 0, 0, 0); record(CLS_ERR_INVALID_BASE, 0, 0, 0, 0); continue; }
-        // code (and palindrome flag) of lookup j: forward windows first, then those of the reverse complement (kmers_map.rs:387-395)
-        auto code_of = [&](uint32_t j, bool& palindrome) -> uint32_t {
-            const bool rc = j >= nf;
-            const uint32_t p = rc ? (nf - 1) - (j - nf) : j;  // window start; the rc list runs backwards over the windows
-            const uint32_t w = p >> 4, s2 = (2 * p) & 31;
-            const uint32_t d0 = packed[w], d1 = packed[w + 1];
-            uint32_t code = (uint32_t)((((uint64_t)d1 << 32) | d0) >> s2) & kmask;
-            uint32_t rcc = __builtin_bitreverse32(code ^ (0xAAAAAAAAu & kmask));
-            rcc = ((rcc >> 1) & 0x55555555u) | ((rcc & 0x55555555u) << 1);
-            rcc >>= (32 - 2 * k);
-            palindrome = code == rcc;
-            return CANON ? (rcc < code ? rcc : code) : (rc ? rcc : code);
-        };
-        // ---- A2a. lookups + distinct k-mers, in passes over hash partitions of the codes: wsid[j] = tip-set id of
-        // window j if it is the FIRST with its code (HashSet<u64> of hashes) and the k-mer is in the index, else 0 ------
-        const uint32_t n_pass = (n_look + pass_codes - 1) / pass_codes;
-        uint32_t ib_t = 0;
-        for (uint32_t pass = 0; pass < n_pass; ++pass) {
-            if (pass) __syncthreads();  // the previous pass' set is no longer probed
-            for (uint32_t i = tid; i < TILE_SET_ENTRIES; i += THREADS) cset[i] = SET_EMPTY;
-            __syncthreads();
-            for (uint32_t j = tid; j < n_look; j += THREADS) {
-                bool palindrome;
-                const uint32_t code = code_of(j, palindrome);
-                if (n_pass != 1 && (uint32_t)(((uint64_t)mix32(code) * n_pass) >> 32) != pass) continue;
-                uint32_t sid = ldx<uint32_t, ADDR32>(direct, code) & SET_ID_MASK;
-                if (STATS) ib_t += 4;
-                if (sid) {
-                    uint32_t pos = (code * 2654435761u) & (TILE_SET_ENTRIES - 1);
-                    for (uint32_t probes = 0;; ++probes) {
-                        if (probes == TILE_SET_ENTRIES) { sh.overflow = 1; sid = 0; break; }  // (a partition that does not fit: spill the read)
-                        const uint32_t old = atomicCAS(&cset[pos], SET_EMPTY, code);
-                        if (old == SET_EMPTY) break;
-                        if (old == code) { sid = 0; break; }
-                        pos = (pos + 1) & (TILE_SET_ENTRIES - 1);
-                    }
-                }
-                wsid[j] = sid ? (sid | ((CANON && !palindrome) ? 0u : 0x80000000u)) : 0u;  // bit 31: the lookup stands for ONE k-mer
-            }
-        }
-        __syncthreads();
-        if (sh.overflow) {  // hand the read to the workspace kernel
-            if (tid == 0) spill_list[atomicAdd(spill_len, 1u)] = r;
-            continue;
-        }
-        // (Measured and rejected: ONE entry per distinct tip set -- every run adding its weight to an LDS table keyed by the
-        // set id, the entries then made from the table.  C5 at 0.1 scale 683 -> 653 k reads/s, at 0.3 scale 575.6 -> 583.1 ms:
-        // the runs of a read are nearly all of different sets already, the second pass only costs.)
-        // ---- A2b. state entries.  Consecutive windows mostly share their tip set (a set's k-mers are the windows between
-        // two mutation boundaries of a lineage): runs of equal set ids among a wavefront's 64 consecutive windows
-        // become ONE entry weighted by the run, and only the run's head reads the 16-byte set record. --------------
-        uint32_t nm_t = 0, nroot_t = 0;
-        uint64_t leafp_t = 0;
-        for (uint32_t base = 0; base < n_look; base += THREADS) {
-            const uint32_t j = base + tid;
-            const uint32_t v = j < n_look ? wsid[j] : 0u;
-            __syncthreads();  // every window of this block is read before entries (xs[g], g <= j) overwrite the same words
-            const uint32_t sid = v & SET_ID_MASK;
-            const uint32_t kw = !sid ? 0u : (v >> 31) ? 1u : 2u;
-            const uint32_t prev_sid = __shfl_up(sid, 1);
-            const bool member = sid != 0;
-            const bool head = member && (lane == 0 || prev_sid != sid);
-            // weight of the run that starts at a head: inclusive prefix sums of kw, run end = lane before the next head / non-member
-            uint32_t ps = kw;
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(ps, o); if ((int)lane >= o) ps += t; }
-            const uint64_t stop = __ballot(head || !member);   // lanes at which a run cannot continue
-            const uint64_t later = lane == 63 ? 0ull : (stop >> (lane + 1));
-            const uint32_t end = later ? lane + (uint32_t)__ffsll((unsigned long long)later) - 1u : 63u;  // last lane of my run (if I am a head)
-            const uint32_t ps_end = __shfl(ps, (int)end);
-            const uint32_t w = head ? ps_end - (ps - kw) : 0u;
-            uint4 sr = uint4{0u, 0xFFFFFFFFu, 0u, 0u};
-            if (head) { sr = ldx<uint4, ADDR32>(sets, sid); if (STATS) ib_t += 16; }
-            const bool has_root = (sr.z >> 31) != 0, has_tips = sr.y != 0xFFFFFFFFu;
-            if (head) { nm_t += w; nroot_t += has_root ? w : 0u; if (STATS) leafp_t += (uint64_t)w * sr.w; }
-            const bool live = head && has_root && has_tips;
-            const uint32_t g = append_slot(live, &sh.n_groups);
-            if (live) {
-                hot[g] = (uint64_t)(sr.y & TILE_TIP_MASK) | ((uint64_t)(sr.z & TILE_TIP_MASK) << TILE_TIP_BITS) | ((uint64_t)w << (2 * TILE_TIP_BITS));
-                xs[g] = sr.x;
-            }
-        }
-        {   // |M|, |M_root| (and the statistics) over the workgroup
-            const uint32_t a = wave_sum(nm_t), b = wave_sum(nroot_t);
-            if (lane == 0) { if (a) atomicAdd(&sh.n_m, a); if (b) atomicAdd(&sh.n_root, b); }
-            if (STATS) {
-                for (int o = 32; o > 0; o >>= 1) leafp_t += ((uint64_t)__shfl_xor((uint32_t)(leafp_t >> 32), o) << 32) | __shfl_xor((uint32_t)leafp_t, o);
-                if (lane == 0 && leafp_t) atomicAdd(&sh.leafp, (unsigned long long)leafp_t);
-            }
-        }
-        __syncthreads();
-        const uint32_t n_m = sh.n_m, n_root = sh.n_root, n_groups = sh.n_groups;
-        uint32_t ib = ib_t;  // per thread; summed at the end
-        auto finish_stats = [&]() {
-            if constexpr (STATS) {
-                const uint32_t w = wave_sum(ib);
-                if (lane == 0 && w) atomicAdd(&sh.ib, w);
-                __syncthreads();
-                put_stats(nk, n_m, n_root, (uint64_t)sh.leafp, sh.ib);
-            }
-        };
-        // ---- B. thresholds (as in place_read_fast) ------------------------------------------------------------------
-        if (n_m == 0) { finish_stats(); record(CLS_UNCLASSIFIABLE_NO_MATCH, 0, 0, 0, 0); continue; }
-        if (n_root == 0) { finish_stats(); record(CLS_UNCLASSIFIABLE_NO_ROOT, 0, 0, 0, 0); continue; }
-        snode_t P = load_node(db.nodes, 0);
-        if (STATS && tid == 0) ib += 32;
-        if (!(P.s[7] & 1u)) { finish_stats(); record(CLS_ERR_ROOT_NO_CHILDREN, 0, 0, 0, 0); continue; }
-        {
-            const double expected = round((double)n_m * prm.min_match_coverage);
-            const uint64_t exp_usize = (expected != expected) ? 0ull : (uint64_t)expected;
-            if ((uint64_t)n_root < exp_usize) { finish_stats(); record(CLS_UNCLASSIFIABLE_COVERAGE, (int32_t)n_root, 0, 0, 0); continue; }
-        }
-        // ---- C. descent ---------------------------------------------------------------------------------------------
-        // Every thread owns the same entries at every level.  ONE pass per level: an entry is narrowed to the clade just
-        // chosen and, in the same breath, counted against the split of that clade's children; then one barrier for the
-        // three sums.  Both children's node records arrive a level ahead (one 64-byte scalar load per level), so the
-        // decision of a level starts the next pass at once.
-        snode_pair_t C = load_node_pair(db.nodes, P.s[2]);  // (a binary tree: the root has its two children in consecutive rows)
-        if (STATS && tid == 0) ib += 64;
-        uint32_t c_ab = 0, c_both = 0;  // k-mers in a | in b << 16; in both (weights: at most 2 * nf < 2^16)
-        {
-            const uint32_t a1 = P.s[6];
-            for (uint32_t j = tid; j < n_groups; j += THREADS) {
-                const uint64_t h = hot[j];
-                const uint32_t lo_ = (uint32_t)h & TILE_TIP_MASK, hi_ = (uint32_t)(h >> TILE_TIP_BITS) & TILE_TIP_MASK, w = (uint32_t)(h >> (2 * TILE_TIP_BITS));
-                const bool ina = lo_ < a1, inb = hi_ >= a1;  // an inactive entry is {MAX, 0}
-                c_ab += (ina ? w : 0u) | ((inb ? w : 0u) << 16);
-                c_both += (ina && inb) ? w : 0u;
-            }
-        }
-        int32_t iteration = 0;
-        for (;;) {
-            ++iteration;
-            if (iteration > prm.max_iterations) { record(CLS_ERR_MAX_ITER, 0, 0, (uint32_t)iteration, 0); break; }
-            const uint32_t m = P.s[3];
-            const uint32_t a0 = P.s[0] + 1, a1 = P.s[6];  // first child = [a0, a1), second = [a1, end of the parent)
-            const uint32_t slot = (uint32_t)iteration % 3u;
-            c_ab = wave_sum(c_ab); c_both = wave_sum(c_both);
-            if (lane == 0) { if (c_ab) atomicAdd(&sh.cnt[slot][0], c_ab); if (c_both) atomicAdd(&sh.cnt[slot][1], c_both); }
-            __syncthreads();
-            const uint32_t t_ab = sh.cnt[slot][0];
-            uint32_t cnt_a = t_ab & 0xFFFFu, cnt_b = t_ab >> 16, both = sh.cnt[slot][1];
-            if (tid < 2) sh.cnt[(slot + 2) % 3u][tid] = 0;  // (read by everyone before the barrier just passed; next used two levels on)
-            if (m == 0) cnt_a = 0;                 // no non-LEAF child: nothing is scored (:322-324)
-            if (m < 2) { cnt_b = 0; both = 0; }   // the second child is a LEAF
-            // one_a - rest_a = |only_a| - |only_b| = -(one_b - rest_b) for either remove_intersection: exactly one child
-            // passes `one > rest` when the two differ, none on a tie
-            const uint32_t only_a = cnt_a - both, only_b = cnt_b - both, U = cnt_a + cnt_b - both;
-            const uint64_t pid = ((uint64_t)P.s[5] << 32) | P.s[4];
-            if (only_a == only_b) {
-                if (iteration == 1) record(CLS_UNCLASSIFIABLE_LEVEL1, 0, 0, 1, 0);
-                else record(CLS_MAX_RESOLUTION, 0, 0, (uint32_t)iteration, pid);
-                break;
-            }
-            const bool right = only_b > only_a;
-            snode_t Pn;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) Pn.s[i] = right ? C.s[8 + i] : C.s[i];
-            if (Pn.s[3] == 0) {  // no non-LEAF child below the chosen clade (update_introspection_node.rs:45-85)
-                const uint32_t cn = right ? cnt_b : cnt_a, on = right ? only_b : only_a;
-                record(CLS_IDENTITY_FOUND, (int32_t)(rm ? on : cn), (int32_t)(rm ? U - cn : U - on), (uint32_t)iteration, ((uint64_t)Pn.s[5] << 32) | Pn.s[4]);
-                break;
-            }
-            C = load_node_pair(db.nodes, Pn.s[2]);  // its children: looked at after the next barrier
-            if (STATS && tid == 0) ib += 64;
-            // narrow every entry to the chosen clade (one 8-byte split half for an entry with tips on both sides of a1)
-            // and count it against the split of that clade's children
-            const uint32_t a1n = Pn.s[6];
-            c_ab = 0; c_both = 0;
-            for (uint32_t j0 = tid; j0 < n_groups; j0 += 4 * THREADS) {
-                uint64_t h[4];
-                uint32_t xv[4];
-                uint2 t[4];
-                bool str[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const uint32_t j = j0 + i * THREADS;
-                    h[i] = j < n_groups ? hot[j] : (uint64_t)TILE_TIP_MASK;  // beyond the end: the inactive entry {MAX, 0}, weight 0
-                }
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const uint32_t j = j0 + i * THREADS;
-                    const uint32_t lo_ = (uint32_t)h[i] & TILE_TIP_MASK, hi_ = (uint32_t)(h[i] >> TILE_TIP_BITS) & TILE_TIP_MASK;
-                    str[i] = lo_ < a1 && hi_ >= a1 && (right || lo_ != a0);
-                    xv[i] = str[i] ? xs[j] : 0u;
-                }
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    t[i] = ld_half<ADDR32>(half, str[i] ? xv[i] : 0u, (str[i] && right) ? 1u : 0u);  // (record 0: the dummy)
-                    if (STATS && str[i]) ib += 8;
-                }
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const uint32_t j = j0 + i * THREADS;
-                    uint32_t lo_ = (uint32_t)h[i] & TILE_TIP_MASK, hi_ = (uint32_t)(h[i] >> TILE_TIP_BITS) & TILE_TIP_MASK;
-                    const uint32_t w = (uint32_t)(h[i] >> (2 * TILE_TIP_BITS));
-                    if (str[i]) { if (!right) hi_ = t[i].x; else lo_ = t[i].x; xs[j] = t[i].y; }
-                    const bool gone = !right ? (lo_ >= a1 || lo_ == a0)    // no tip strictly below the first child
-                                             : (hi_ < a1 || lo_ == a1);    // nothing in the second child, or it is the tip itself
-                    if (gone) { lo_ = TILE_TIP_MASK; hi_ = 0; }
-                    if ((str[i] || gone) && j < n_groups) hot[j] = (uint64_t)lo_ | ((uint64_t)hi_ << TILE_TIP_BITS) | ((uint64_t)w << (2 * TILE_TIP_BITS));
-                    const bool ina = lo_ < a1n, inb = hi_ >= a1n;
-                    c_ab += (ina ? w : 0u) | ((inb ? w : 0u) << 16);
-                    c_both += (ina && inb) ? w : 0u;
-                }
-            }
-            P = Pn;
-        }
-        finish_stats();
-    }
-}
-
 // ---- read-length classes ----------------------------------------------------------------------
 // One thread per read: reads are binned by their k-mer count into the kernel wide enough for
 // them (class lists in device memory; nothing returns to the host).  Reads no kernel can hold
@@ -2697,10 +2390,6 @@ int fast_mode(const DbDev& db) { return db.direct == nullptr ? 2 : (db.direct16 
 bool mode_canonical(int mode) { return mode == 1 || mode == 4; }
 // table bits of a wave-per-read class: the narrow class needs fewer on a strand-symmetric index (one lookup per window)
 int set_bits_of(const DbDev& db, int c) { return (c == 0 && use_fast(db) && mode_canonical(fast_mode(db))) ? NARROW_CANON_BITS : CLS_SET_BITS[c]; }
-// the LDS-tiled long-read kernel: binary FMT_SPLIT index with a direct table, pre-order indices in 24 bits
-bool use_tile(const DbDev& db) {
-    return db.format == FMT_SPLIT && db.binary_tree && db.direct != nullptr && db.n_nodes < TILE_TIP_MASK && !tuning().no_tile;
-}
 uint32_t seq_cap_of(const DbDev& db, int c) { return (2 * (64 * CLS_SLOTS[c] / 2 + db.k) + 15) & ~15u; }
 // fast path: L <= 32*SLOTS + k - 1 ascii bytes (+ padding so that the 16-byte packer can over-read)
 uint32_t ascii_cap_of(const DbDev& db, int c) {
@@ -2762,9 +2451,12 @@ size_t blk_smem(const DbDev& db) {
 std::string dominant_kernel_name(const DbDev& db, bool stats, const PlacePlan* plan) {
     const std::string sl = std::to_string(CLS_SLOTS[0]) + ", " + std::to_string(set_bits_of(db, 0)) + ", " + (stats ? "true" : "false");
     auto b = [](bool v) { return std::string(v ? "true" : "false"); };
-    if (plan && plan->grid_tile && plan->tile_slots) return regtile_kernel_name(db, stats, plan->tile_threads, plan->tile_slots);
-    if (plan && plan->grid_tile)  // a launch provisioned for long reads: the LDS-tiled kernel is the one that is timed
-        return "place_tile_kernel<" + std::to_string(plan->tile_threads) + ", " + b(db.canonical != 0) + ", " + b(stats) + ", " + b(db.addr32 != 0) + ">";
+    if ((!plan || !plan->grid_tile) && tuning().time_class == 2) {
+        const std::string bl = std::to_string(BLK_WAVES) + ", " + std::to_string(BLK_SLOTS) + ", " + std::to_string(BLK_SET_BITS) + ", " + b(stats);
+        if (db.format == FMT_SPLIT) return "place_block_kernel<" + bl + ", " + b(db.binary_tree != 0) + ", true>";
+        return "place_block_kernel<" + bl + ", " + b(db.max_nonleaf_arity <= 2) + ", false>";
+    }
+    if (plan && plan->grid_tile) return tile_kernel_name(db, stats, plan->tile_threads);  // a launch provisioned for long reads: the LDS-tiled kernel is the one that is timed
     if (use_fast(db))
         return "place_fast_kernel<" + sl + ", " + b(fast_mode(db) == 2 || db.addr32) + ", " + std::to_string(fast_mode(db)) + ", " + b(!db.binary_tree) + ">";
     if (db.format == FMT_SPLIT) return "place_split_kernel<" + sl + ", " + b(!db.binary_tree) + ">";
@@ -2830,28 +2522,10 @@ PlacePlan plan_place(const DbDev& db, uint32_t n_reads, uint32_t n_cu, bool stat
     w += child_words;
     w += w & 1;
     // LDS-tiled long-read class (binary FMT_SPLIT index with a direct table): as many lookups per read as 160 KB of LDS hold
-    if (long_cap > MAX_READ_KMERS && n_long && regtile_usable(db)) {  // the register-tiled kernel (cls_tile.hip)
-        const RegTilePlan rt = regtile_plan(db, long_cap, n_long, n_cu, stats);
-        p.grid_tile = rt.grid; p.tile_threads = rt.threads; p.tile_slots = rt.slots; p.tile_lookups = rt.lookups;
-        p.tile_bases = rt.bases; p.tile_smem = rt.smem; p.tile_cap_kmers = rt.cap_kmers;
-    } else if (long_cap > MAX_READ_KMERS && n_long && use_tile(db)) {
-        const bool canon = db.canonical != 0;
-        const uint32_t want = canon ? long_cap / 2 : long_cap;  // lookups of the longest read (canonical: one per window)
-        auto bases_of = [&](uint32_t look) { return (canon ? look : look / 2) + db.k; };
-        uint32_t look = want;
-        const size_t lds_max = 160 * 1024 - sizeof(TileSh) - 256;
-        if (tile_smem(look, bases_of(look)) > lds_max) {
-            look = (uint32_t)((lds_max - 4ull * TILE_SET_ENTRIES - 64 - 4ull * 8) / 12);
-            while (look > 64 && tile_smem(look, bases_of(look)) > lds_max) look -= 64;
-        }
-        look = std::min<uint32_t>(look, 32767u);  // weights are summed in 16-bit halves
-        p.tile_lookups = look;
-        p.tile_bases = bases_of(look);
-        p.tile_smem = tile_smem(p.tile_lookups, p.tile_bases);
-        const uint32_t per_cu = (uint32_t)std::min<size_t>(2, (160 * 1024) / (p.tile_smem + sizeof(TileSh) + 256));
-        p.tile_threads = per_cu >= 2 ? 512u : 1024u;
-        p.grid_tile = std::max<uint32_t>(1, std::min<uint32_t>(n_long, n_cu * std::max(1u, per_cu)));
-        p.tile_cap_kmers = canon ? 2 * look : look;
+    if (long_cap > MAX_READ_KMERS && n_long && tile_usable(db)) {  // (cls_tile.hip)
+        const TilePlan tp = tile_plan(db, long_cap, n_long, n_cu);
+        p.grid_tile = tp.grid; p.tile_threads = tp.threads; p.tile_lookups = tp.lookups;
+        p.tile_bases = tp.bases; p.tile_smem = tp.smem; p.tile_cap_kmers = tp.cap_kmers;
     }
     // long-read class: per workgroup two state buffers (the distinct-hit set shares the second) + child counters
     if (long_cap > MAX_READ_KMERS && n_long) {
@@ -2980,11 +2654,11 @@ hipError_t launch_place(const DbDev& db, const PlaceParams& prm, const PlacePlan
     };
     // the timed kernel (cls_db_kernel_time): the LDS-tiled long-read kernel in a launch provisioned for long reads,
     // else the wave-per-read kernel of the <= 320-k-mer class
-    const bool time_tile = plan.grid_tile != 0;
-    if (ev_start && !time_tile) (void)hipEventRecord(ev_start, stream);
+    const bool time_tile = plan.grid_tile != 0, time_blk = !time_tile && tuning().time_class == 2;  // (time_class 2: a bench of gene-length reads times the workgroup-per-read kernel)
+    if (ev_start && !time_tile && !time_blk) (void)hipEventRecord(ev_start, stream);
     if (set_bits_of(db, 0) != CLS_SET_BITS[0]) launch_class(std::integral_constant<int, CLS_SLOTS[0]>{}, std::integral_constant<int, NARROW_CANON_BITS>{}, 0);
     else launch_class(std::integral_constant<int, CLS_SLOTS[0]>{}, std::integral_constant<int, CLS_SET_BITS[0]>{}, 0);
-    if (ev_stop && !time_tile) (void)hipEventRecord(ev_stop, stream);
+    if (ev_stop && !time_tile && !time_blk) (void)hipEventRecord(ev_stop, stream);
     if (hipGetLastError() != hipSuccess) return hipErrorLaunchFailure;
     launch_class(std::integral_constant<int, CLS_SLOTS[1]>{}, std::integral_constant<int, CLS_SET_BITS[1]>{}, 1);
     if (hipGetLastError() != hipSuccess) return hipErrorLaunchFailure;
@@ -2992,6 +2666,7 @@ hipError_t launch_place(const DbDev& db, const PlaceParams& prm, const PlacePlan
         const dim3 grid(plan.grid_blk), block(64 * BLK_WAVES);
         const uint32_t seq_cap = blk_seq_cap(db);
         const size_t smem = blk_smem(db);
+        if (ev_start && time_blk) (void)hipEventRecord(ev_start, stream);
 #define CLS_LAUNCH_BLK(ST, BI, SP)                                                                                              \
     do {                                                                                                                        \
         auto kfn = place_block_kernel<BLK_WAVES, BLK_SLOTS, BLK_SET_BITS, ST, BI, SP>;                                          \
@@ -3004,30 +2679,13 @@ hipError_t launch_place(const DbDev& db, const PlaceParams& prm, const PlacePlan
         else if (binary) { if (st) CLS_LAUNCH_BLK(true, true, false); else CLS_LAUNCH_BLK(false, true, false); }
         else { if (st) CLS_LAUNCH_BLK(true, false, false); else CLS_LAUNCH_BLK(false, false, false); }
 #undef CLS_LAUNCH_BLK
+        if (ev_stop && time_blk) (void)hipEventRecord(ev_stop, stream);
     }
     if (plan.grid_tile) {  // class 3: long reads, every state in LDS; reads it cannot hold are appended to class 4's list
         if (hipGetLastError() != hipSuccess) return hipErrorLaunchFailure;
         if (ev_start) (void)hipEventRecord(ev_start, stream);
-        if (plan.tile_slots) {
-            const RegTilePlan rt{plan.tile_threads, plan.tile_slots, plan.tile_lookups, plan.tile_bases, plan.tile_cap_kmers, plan.grid_tile, plan.tile_smem};
-            regtile_launch(db, prm, rt, st, d_bases, d_offsets, lists[3], counts + 3, d_out, d_stats, lists[4], counts + 4, stream);
-        } else {
-#define CLS_LAUNCH_TILE(TH, CN, ST, A32)                                                                                          \
-    do {                                                                                                                          \
-        auto kfn = place_tile_kernel<TH, CN, ST, A32>;                                                                            \
-        (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)plan.tile_smem);             \
-        hipLaunchKernelGGL(kfn, dim3(plan.grid_tile), dim3(TH), plan.tile_smem, stream, db, prm, d_bases, d_offsets, lists[3],    \
-                           counts + 3, d_out, d_stats, plan.tile_lookups, plan.tile_bases,                                       \
-                           (uint32_t)std::max(1, tuning().tile_pass_codes), lists[4], counts + 4);                                \
-    } while (0)
-#define CLS_LAUNCH_TILE3(TH, CN, ST) do { if (db.addr32) CLS_LAUNCH_TILE(TH, CN, ST, true); else CLS_LAUNCH_TILE(TH, CN, ST, false); } while (0)
-#define CLS_LAUNCH_TILE2(TH, CN) do { if (st) CLS_LAUNCH_TILE3(TH, CN, true); else CLS_LAUNCH_TILE3(TH, CN, false); } while (0)
-        if (plan.tile_threads == 512) { if (db.canonical) CLS_LAUNCH_TILE2(512, true); else CLS_LAUNCH_TILE2(512, false); }
-        else { if (db.canonical) CLS_LAUNCH_TILE2(1024, true); else CLS_LAUNCH_TILE2(1024, false); }
-#undef CLS_LAUNCH_TILE2
-#undef CLS_LAUNCH_TILE3
-#undef CLS_LAUNCH_TILE
-        }
+        const TilePlan tp{plan.tile_threads, plan.tile_lookups, plan.tile_bases, plan.tile_cap_kmers, plan.grid_tile, plan.tile_smem};
+        tile_launch(db, prm, tp, st, d_bases, d_offsets, lists[3], counts + 3, d_out, d_stats, lists[4], counts + 4, stream);
         if (ev_stop) (void)hipEventRecord(ev_stop, stream);
     }
     if (plan.grid_long) {  // class 4: reads beyond what the LDS holds (and every long read of the other index shapes): state in the workspace

@@ -1,21 +1,23 @@
-// Long reads, register-tiled: one WORKGROUP per read, every per-k-mer state in REGISTERS (gfx950 / CDNA4, wave64).
+// Long reads, LDS-tiled: one WORKGROUP per read, every per-k-mer state in LDS (gfx950 / CDNA4, wave64).
 // BASELINE config 5 (10 kb reads, k = 15, deep tree); binary FMT_SPLIT indexes with a direct table.
 //
 // The algorithm is place_sequence.rs:42-601 as in cls_kernels.hip (A: k-mers + lookup + distinct hashes,
-// B: thresholds, C: descent).  What this kernel is built around:
-//   * a read's state is one ENTRY per run of consecutive windows that share a tip set: {first tip, last tip, weight,
-//     split record} in three registers of the thread that owns the run's first window; the LDS only holds the
-//     packed read and the set of codes that makes the k-mers distinct (35 KB: several reads per CU, whose dependent
-//     reads overlap -- the LDS-resident predecessor held one read per CU and waited out every round trip);
-//   * the front issues ALL of a thread's table lookups at once, then the set records four at a time: three or four
-//     round trips per read instead of one per 1024 windows;
-//   * a level of the descent needs only the SIGN of |K_a| - |K_b| (both `remove_intersection` values):
-//     one signed sum per thread, ONE wave reduction, one LDS atomic per wave, one barrier; the three counts of the
-//     record are taken once, at the level the descent ends at;
-//   * narrowing an entry to the chosen child is one 8-byte split half for an entry with tips on both sides
-//     (kmers_map.rs:189-203 answered from the split tree), all of a thread's reads of a level in flight together.
+// B: thresholds, C: descent).  Layout: the read packed 2 bits per base, a set of codes that makes the k-mers distinct
+// (filled in PASSES over hash partitions of the codes: a read of any length), and one ENTRY per run of consecutive
+// windows that share a tip set: {first tip << 8 | weight, last tip << 8} + the set's split record, 12 bytes of LDS.
+// What the descent is built around (on a 150-level ladder tree a level costs what its dependent chain costs):
+//   * a level is DECIDED by the sign of |K_a| - |K_b| (both `remove_intersection` values): one pass
+//     over the entries, two compares each, ONE packed sum per thread, one wave reduction, one barrier; the three counts
+//     of the record are taken once, at the level the descent ends at;
+//   * narrowing touches only an entry with a tip OUTSIDE the chosen child; it dies, or -- tips on both sides -- needs
+//     ONE 8-byte half of its split record (kmers_map.rs:189-203 answered from the split tree).  That read is
+//     ASYNCHRONOUS to the level loop: the entry becomes PENDING (weight parked in HI's low byte, the counts skip it), the
+//     thread keeps the load in flight and goes on.  The next level's counts are exact over the settled entries and
+//     off by at most the pending weight W: with |d| > W the level is decided without the halves (on a ladder nearly
+//     every level: margins are thousands of k-mers, a level's straddlers a few hundred) and they are applied a
+//     level later, long arrived; otherwise the workgroup settles them first and counts again.
 // A read whose codes overflow a partition of the set (adversarial input only) goes to the workspace kernel through
-// the spill list, as before.
+// the spill list.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -30,17 +32,20 @@ namespace cls {
 
 namespace {
 
-#ifndef RT_MIN_WAVES
-#define RT_MIN_WAVES 4
-#endif
-constexpr uint32_t RT_SET_ENTRIES = 8192;   // LDS set of codes per pass (32 KB)
+constexpr uint32_t RT_SET_ENTRIES = 4096;   // LDS set of codes per pass (16 KB)
 constexpr uint32_t RT_TIP_BITS = 24;        // pre-order indices an entry holds (tip << 8 | weight)
+constexpr uint32_t RT_TIP_MASK = (1u << RT_TIP_BITS) - 1;
 constexpr uint32_t RT_DEAD_LO = 0xFFFFFF00u;
-constexpr uint32_t SET_EMPTY_RT = 0xFFFFFFFFu;
+constexpr uint32_t RT_SET_EMPTY = 0xFFFFFFFFu;
+#ifndef RT_LOOK_N
+#define RT_LOOK_N 5
+#endif
+constexpr int RT_LOOK = RT_LOOK_N;          // table lookups / set records a thread keeps in flight
 
-struct RegSh {
-    int32_t cnt[3];          // rotating per-level sums of |K_a| - |K_b|
+struct RtSh {
+    uint32_t cnt[3][2];      // rotating per-round sums {k-mers with a tip before the split | at or after it << 16, pending weight}
     uint32_t fin[3];         // the three counts of the final level
+    uint32_t n_groups;
     uint32_t n_m, n_root;
     uint32_t overflow;
     uint32_t ib;
@@ -48,91 +53,36 @@ struct RegSh {
 };
 
 __host__ __device__ inline uint32_t rt_packed_words(uint32_t max_bases) { return ((max_bases + 15) / 16 + 2 + 3) & ~3u; }
-__host__ __device__ inline size_t rt_smem(uint32_t max_bases, uint32_t max_lookups) { return 4ull * rt_packed_words(max_bases) + 4ull * RT_SET_ENTRIES + 4ull * max_lookups; }
-
-// 8-byte half of split record x as ONE read (volatile: or the compiler splits it into two dwords and sinks the second
-// into a branch with its own wait).
-template <bool ADDR32>
-__device__ __forceinline__ uint2 ld_half_v(const uint32_t* half, uint32_t x, uint32_t right) {
-    uint64_t v;
-    if constexpr (ADDR32) v = *reinterpret_cast<const volatile uint64_t*>(reinterpret_cast<const char*>(half) + (uint32_t)((2 * x + right) * 8u));
-    else v = *(reinterpret_cast<const volatile uint64_t*>(half) + (2ull * x + right));
-    return uint2{(uint32_t)v, (uint32_t)(v >> 32)};
+// dynamic LDS for reads of up to `max_lookups` table lookups and `max_bases` bases
+__host__ __device__ inline size_t rt_smem(uint32_t max_lookups, uint32_t max_bases) {
+    return 4ull * rt_packed_words(max_bases) + 4ull * RT_SET_ENTRIES + 8ull * max_lookups + 4ull * max_lookups + 16;
 }
 
-// The thread's share of |K_a| - |K_b| against the split a1n of a clade whose entries are narrowed to it (a1ns = a1n << 8;
-// wbm = 0xFF when the clade's second child is scored: a LEAF child is not, place_sequence.rs:322-324).
-template <int SLOTS>
-__device__ __forceinline__ int32_t count_level(const uint32_t (&LO)[SLOTS], const uint32_t (&HI)[SLOTS], uint32_t a1ns, uint32_t wbm) {
-    uint32_t da = 0, db = 0;
-#pragma unroll
-    for (int i = 0; i < SLOTS; ++i) {
-        const uint32_t w = LO[i] & 0xFFu;
-        da += LO[i] < a1ns ? w : 0u;
-        db += HI[i] >= a1ns ? w : 0u;
-    }
-    return (int32_t)da - (int32_t)(wbm ? db : 0u);
+// position of this thread's element in a list that all threads of the workgroup append to (wave-aggregated)
+__device__ __forceinline__ uint32_t rt_append(bool keep, uint32_t* counter, uint32_t lane) {
+    const uint64_t m = __ballot(keep);
+    if (!m) return 0;
+    const int leader = __ffsll((unsigned long long)m) - 1;
+    uint32_t base = 0;
+    if ((int)lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(m));
+    base = __shfl(base, leader);
+    return base + (uint32_t)__popcll(m & ((1ull << lane) - 1));
 }
 
-// One level of the descent for a thread's entries: narrow each to the chosen child (RIGHT: [a1, end), else [a0, a1)).
-// Only an entry with a tip OUTSIDE the chosen child is touched -- going left one whose last tip lies at or after a1, going
-// right one whose first tip lies before a1 (one compare per entry, and a whole wavefront skips an entry slot none of its
-// lanes is concerned in); it dies, or, with tips on both sides, reads the 8-byte half of its split record for the side
-// taken: {the tip next to a1 on that side, the split of that part}.  All of a thread's reads of a level are in flight together.
-// a0s = a0 << 8 | 0xFF, a1s = a1 << 8 (the entries hold tip << 8 | weight).
-template <bool RIGHT, int SLOTS, bool ADDR32, bool STATS>
-__device__ __forceinline__ void narrow_level(uint32_t (&LO)[SLOTS], uint32_t (&HI)[SLOTS], uint32_t* __restrict__ xs_t, uint32_t stride, const uint32_t* __restrict__ half,
-                                             uint32_t a0s, uint32_t a1s, uint32_t& ib) {
-    uint2 t[SLOTS];
-    auto concerned = [&](int i) { return RIGHT ? LO[i] < a1s : HI[i] >= a1s; };  // (a dead entry {MAX, 0} never is)
-#pragma unroll
-    for (int i = 0; i < SLOTS; ++i) {
-        const bool cnd = concerned(i);
-        if (__ballot(cnd) == 0) continue;
-        // tips on both sides (going left an entry whose first tip is the first child itself dies whatever lies beyond)
-        const bool str = cnd && (RIGHT ? HI[i] >= a1s : (LO[i] < a1s && LO[i] > a0s));
-#ifdef RT_EXPERIMENT_NO_READS
-        if (false) {
-#else
-        if (str) {
-#endif
-            t[i] = ld_half_v<ADDR32>(half, xs_t[(uint32_t)i * stride], RIGHT ? 1u : 0u);
-            if (STATS) ib += 8;
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < SLOTS; ++i) {
-        const bool cnd = concerned(i);
-        if (__ballot(cnd) == 0) continue;
-        if (cnd) {
-            uint32_t lo = LO[i], hi = HI[i];
-            const bool str = RIGHT ? hi >= a1s : (lo < a1s && lo > a0s);
-            bool alive;
-            if (RIGHT) {
-                if (str) lo = (t[i].x << 8) | (lo & 0xFFu);   // the first tip at or after a1
-                alive = str && lo > (a1s | 0xFFu);           // a tip strictly below the second child (lo == a1: the child itself is the tip)
-            } else {
-                if (str) hi = t[i].x << 8;                     // the last tip before a1
-                alive = str;                                   // (a0 < lo < a1)
-            }
-            if (str) xs_t[(uint32_t)i * stride] = t[i].y;
-            LO[i] = alive ? lo : RT_DEAD_LO;
-            HI[i] = alive ? hi : 0u;
-        }
-    }
-}
-
-template <int THREADS, int SLOTS, bool CANON, bool STATS, bool ADDR32>
-__global__ __launch_bounds__(THREADS, RT_MIN_WAVES) void place_regtile_kernel(DbDev db, PlaceParams prm, const uint8_t* __restrict__ bases,
-                                                                const uint64_t* __restrict__ offsets, const uint32_t* __restrict__ list,
-                                                                const uint32_t* __restrict__ list_len, cls_placement* __restrict__ out,
-                                                                cls_query_stats* __restrict__ stats, uint32_t max_bases, uint32_t pass_codes,
-                                                                uint32_t* __restrict__ spill_list, uint32_t* __restrict__ spill_len) {
+template <int THREADS, bool CANON, bool STATS, bool ADDR32>
+__global__ __launch_bounds__(THREADS) void place_tile_kernel(DbDev db, PlaceParams prm, const uint8_t* __restrict__ bases,
+                                                             const uint64_t* __restrict__ offsets, const uint32_t* __restrict__ list,
+                                                             const uint32_t* __restrict__ list_len, cls_placement* __restrict__ out,
+                                                             cls_query_stats* __restrict__ stats, uint32_t max_lookups, uint32_t max_bases,
+                                                             uint32_t pass_codes, uint32_t* __restrict__ spill_list, uint32_t* __restrict__ spill_len) {
     extern __shared__ __align__(16) uint8_t smem[];
-    __shared__ RegSh sh;
+    __shared__ RtSh sh;
     uint32_t* const packed = reinterpret_cast<uint32_t*>(smem);
     uint32_t* const cset = packed + rt_packed_words(max_bases);
-    uint32_t* const xs = cset + RT_SET_ENTRIES;  // per lookup: its tip-set id during the front, then the split record of the entry it heads
+    uint2* const ent = reinterpret_cast<uint2*>(cset + RT_SET_ENTRIES);            // {LO = first tip << 8 | weight, HI = last tip << 8 | pending weight}
+    uint32_t* const xs = reinterpret_cast<uint32_t*>(ent + max_lookups);           // split record of the entry's set
+    uint32_t* const wsid = xs;  // front only: per window its tip-set id | bit 31 (the lookup stands for ONE k-mer) if it is the first with its code, else 0
+    const uint32_t tid = threadIdx.x, lane = tid & 63;
     const uint32_t k = db.k;
     const uint32_t kmask = (1u << (2 * k)) - 1u;  // k <= 15
     const uint32_t* __restrict__ direct = db.direct;
@@ -142,9 +92,6 @@ __global__ __launch_bounds__(THREADS, RT_MIN_WAVES) void place_regtile_kernel(Db
     const uint32_t n_list = *list_len;
     for (uint32_t li = blockIdx.x; li < n_list; li += gridDim.x) {
         __syncthreads();  // the previous read's use of the LDS is over
-        uint32_t tid = threadIdx.x;
-        asm volatile("" : "+v"(tid));  // (opaque per read: or the 2 * SLOTS window indices are hoisted out of this loop and live, spilled, through the descent)
-        const uint32_t lane = tid & 63;
         const uint32_t r = list[li];
         const uint64_t b0 = offsets[r], L64 = offsets[r + 1] - b0;
         auto put_stats = [&](uint32_t nk_, uint32_t nm, uint32_t nr, uint64_t lp, uint32_t ibytes) {
@@ -163,11 +110,11 @@ __global__ __launch_bounds__(THREADS, RT_MIN_WAVES) void place_regtile_kernel(Db
                 o[2] = clade;
             }
         };
-        // (classification keeps L >= k and the lookups within the slots; checked all the same: never trust a list)
+        // (classification keeps L >= k and the lookups within max_lookups; checked all the same: never trust a list)
         if (L64 < k || L64 > max_bases) { put_stats(0, 0, 0, 0, 0); record(L64 < k ? CLS_ERR_TOO_FEW_KMERS : CLS_ERR_READ_TOO_LONG, 0, 0, 0, 0); continue; }
         const uint32_t L = (uint32_t)L64, nf = L - k + 1, nk = 2 * nf;
         const uint32_t n_look = CANON ? nf : nk;
-        if (n_look > (uint32_t)(THREADS * SLOTS)) { put_stats(nk, 0, 0, 0, 0); record(CLS_ERR_READ_TOO_LONG, 0, 0, 0, 0); continue; }
+        if (n_look > max_lookups) { put_stats(nk, 0, 0, 0, 0); record(CLS_ERR_READ_TOO_LONG, 0, 0, 0, 0); continue; }
         // ---- A1. load, validate (reverse_complement panics on non-ACGT, kmers_map.rs:440), pack 2 bits per base ----
         bool bad = false;
         const uint32_t n_words = (L + 15) >> 4;
@@ -185,8 +132,9 @@ __global__ __launch_bounds__(THREADS, RT_MIN_WAVES) void place_regtile_kernel(Db
             }
             packed[w] = acc;
         }
-        if (tid == 0) { sh.n_m = 0; sh.n_root = 0; sh.overflow = 0; sh.ib = 0; sh.leafp = 0; }
-        if (tid < 3) { sh.cnt[tid] = 0; sh.fin[tid] = 0; }
+        if (tid == 0) { sh.n_groups = 0; sh.n_m = 0; sh.n_root = 0; sh.overflow = 0; sh.ib = 0; sh.leafp = 0; }
+        if (tid < 6) (&sh.cnt[0][0])[tid] = 0;
+        if (tid < 3) sh.fin[tid] = 0;
         if (__syncthreads_or(bad ? 1 : 0)) { put_stats(0, 0, 0, 0, 0); record(CLS_ERR_INVALID_BASE, 0, 0, 0, 0); continue; }
         // code (and palindrome flag) of lookup j: forward windows first, then those of the reverse complement (kmers_map.rs:387-395)
         auto code_of = [&](uint32_t j, bool& palindrome) -> uint32_t {
@@ -201,49 +149,43 @@ __global__ __launch_bounds__(THREADS, RT_MIN_WAVES) void place_regtile_kernel(Db
             palindrome = code == rcc;
             return CANON ? (rcc < code ? rcc : code) : (rc ? rcc : code);
         };
-        // ---- A2a. the thread's lookups, five at a time: window i * THREADS + tid -> its word of xs = tip-set id | bit 31 when the
-        // lookup stands for ONE k-mer (a palindrome, or an index that is not strand-symmetric); 0: not in the index ----
+        // ---- A2a. the table lookups, RT_LOOK per thread in flight: wsid[j] = tip-set id | bit 31 when the lookup stands
+        // for ONE k-mer (a palindrome, or an index that is not strand-symmetric); 0: the k-mer is not in the index ----
         uint32_t ib = 0;  // per thread; summed at the end
+        for (uint32_t j0 = tid; j0 < n_look; j0 += RT_LOOK * THREADS) {
+            uint32_t sid[RT_LOOK];
+            bool pal[RT_LOOK];
 #pragma unroll
-        for (int c0 = 0; c0 < SLOTS; c0 += 5) {
-            __builtin_amdgcn_sched_barrier(0);  // (five lookups in flight per thread, 2560 per workgroup: enough, and few registers)
-            uint32_t ws[5];
-#pragma unroll
-            for (int q = 0; q < 5; ++q) {
-                const uint32_t j = (uint32_t)(c0 + q) * THREADS + tid;
-                ws[q] = 0;
-                if (c0 + q < SLOTS && j < n_look) {
-                    bool palindrome;
-                    const uint32_t code = code_of(j, palindrome);
-                    const uint32_t sid = ldx<uint32_t, ADDR32>(direct, code) & SET_ID_MASK;
-                    if (STATS) ib += 4;
-                    ws[q] = sid ? (sid | ((CANON && !palindrome) ? 0u : 0x80000000u)) : 0u;
-                }
+            for (int q = 0; q < RT_LOOK; ++q) {
+                const uint32_t j = j0 + q * THREADS;
+                sid[q] = 0; pal[q] = false;
+                if (j < n_look) { sid[q] = ldx<uint32_t, ADDR32>(direct, code_of(j, pal[q])) & SET_ID_MASK; if (STATS) ib += 4; }
             }
 #pragma unroll
-            for (int q = 0; q < 5; ++q) if (c0 + q < SLOTS) xs[(uint32_t)(c0 + q) * THREADS + tid] = ws[q];  // (a thread only ever touches its own words of xs)
+            for (int q = 0; q < RT_LOOK; ++q) {
+                const uint32_t j = j0 + q * THREADS;
+                if (j < n_look) wsid[j] = sid[q] ? (sid[q] | ((CANON && !pal[q]) ? 0u : 0x80000000u)) : 0u;
+            }
         }
         // ---- A2a'. distinct k-mers (HashSet<u64> of hashes, kmers_map.rs:273-311): the codes that are in the index go
-        // through an LDS set, in PASSES over hash partitions of the codes (a read of any length); a later window with
-        // the same code drops out ----
+        // through an LDS set, in passes over hash partitions of the codes; a later window with the same code drops out
+        // (a thread only ever touches its own words of wsid: no barrier between the lookups and the passes) ----
         const uint32_t n_pass = (n_look + pass_codes - 1) / pass_codes;
         for (uint32_t pass = 0; pass < n_pass; ++pass) {
             if (pass) __syncthreads();  // the previous pass' set is no longer probed
-            for (uint32_t i = tid; i < RT_SET_ENTRIES; i += THREADS) cset[i] = SET_EMPTY_RT;
+            for (uint32_t i = tid; i < RT_SET_ENTRIES; i += THREADS) cset[i] = RT_SET_EMPTY;
             __syncthreads();
-#pragma unroll 1
             for (uint32_t j = tid; j < n_look; j += THREADS) {
-                if (xs[j] == 0) continue;
+                if (wsid[j] == 0) continue;
                 bool palindrome;
                 const uint32_t code = code_of(j, palindrome);
                 if (n_pass != 1 && (uint32_t)(((uint64_t)mix32(code) * n_pass) >> 32) != pass) continue;
                 uint32_t pos = (code * 2654435761u) & (RT_SET_ENTRIES - 1);
-#pragma unroll 1
                 for (uint32_t probes = 0;; ++probes) {
-                    if (probes == RT_SET_ENTRIES) { sh.overflow = 1; xs[j] = 0; break; }  // (a partition that does not fit: spill the read)
-                    const uint32_t old = atomicCAS(&cset[pos], SET_EMPTY_RT, code);
-                    if (old == SET_EMPTY_RT) break;
-                    if (old == code) { xs[j] = 0; break; }
+                    if (probes == RT_SET_ENTRIES) { sh.overflow = 1; wsid[j] = 0; break; }  // (a partition that does not fit: spill the read)
+                    const uint32_t old = atomicCAS(&cset[pos], RT_SET_EMPTY, code);
+                    if (old == RT_SET_EMPTY) break;
+                    if (old == code) { wsid[j] = 0; break; }
                     pos = (pos + 1) & (RT_SET_ENTRIES - 1);
                 }
             }
@@ -255,26 +197,22 @@ __global__ __launch_bounds__(THREADS, RT_MIN_WAVES) void place_regtile_kernel(Db
         }
         // ---- A2b. entries.  Consecutive windows mostly share their tip set (a set's k-mers are the windows between two
         // mutation boundaries of a lineage): runs of equal set ids among a wavefront's 64 consecutive windows become
-        // ONE entry weighted by the run, held by the thread of the run's first window; only that thread reads the
-        // 16-byte set record (four records in flight per thread).  Entry = {LO = first tip << 8 | weight, HI = last
-        // tip << 8} in registers + its split record in the thread's word of xs (only an entry with tips on both sides of a
-        // split needs it: one in fifty per level); no entry / dead entry = {RT_DEAD_LO, 0}: below no split, above none. ----
-        uint32_t LO[SLOTS], HI[SLOTS];
+        // ONE entry weighted by the run, and only the run's head reads the 16-byte set record (RT_LOOK records in
+        // flight per thread).  The entries are appended to `ent` / `xs`; xs lies over wsid: a block of RT_LOOK *
+        // THREADS windows is read by everyone before any entry of it is written (entry index <= window index). ----
         uint32_t nm_t = 0, nroot_t = 0;
         uint64_t leafp_t = 0;
+        for (uint32_t jb = 0; jb < n_look; jb += RT_LOOK * THREADS) {
+            uint32_t v[RT_LOOK];
 #pragma unroll
-        for (int c0 = 0; c0 < SLOTS; c0 += 4) {
-            __builtin_amdgcn_sched_barrier(0);  // (one chunk's records in flight, not all of them: registers)
-            uint4 sr[4];
-            uint32_t wq[4];
+            for (int q = 0; q < RT_LOOK; ++q) { const uint32_t j = jb + q * THREADS + tid; v[q] = j < n_look ? wsid[j] : 0u; }
+            __syncthreads();
+            uint4 sr[RT_LOOK];
+            uint32_t wq[RT_LOOK];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int i = c0 + q;
-                if (i >= SLOTS) break;
-                const uint32_t j = (uint32_t)i * THREADS + tid;
-                const uint32_t v = j < n_look ? xs[j] : 0u;
-                const uint32_t sid = v & SET_ID_MASK;
-                const uint32_t kw = !sid ? 0u : (v >> 31) ? 1u : 2u;
+            for (int q = 0; q < RT_LOOK; ++q) {
+                const uint32_t sid = v[q] & SET_ID_MASK;
+                const uint32_t kw = !sid ? 0u : (v[q] >> 31) ? 1u : 2u;
                 const uint32_t prev_sid = __shfl_up(sid, 1);
                 const bool member = sid != 0;
                 const bool head = member && (lane == 0 || prev_sid != sid);
@@ -291,17 +229,17 @@ __global__ __launch_bounds__(THREADS, RT_MIN_WAVES) void place_regtile_kernel(Db
                 if (head) { sr[q] = ldx<uint4, ADDR32>(sets, sid); if (STATS) ib += 16; }
             }
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int i = c0 + q;
-                if (i >= SLOTS) break;
+            for (int q = 0; q < RT_LOOK; ++q) {
                 const uint32_t w = wq[q];
                 const bool has_root = (sr[q].z >> 31) != 0, has_tips = sr[q].y != 0xFFFFFFFFu;
                 nm_t += w; nroot_t += has_root ? w : 0u;
                 if (STATS) leafp_t += (uint64_t)w * sr[q].w;
                 const bool live = w != 0 && has_root && has_tips;
-                LO[i] = live ? ((sr[q].y & ((1u << RT_TIP_BITS) - 1)) << 8) | w : RT_DEAD_LO;
-                HI[i] = live ? (sr[q].z & ((1u << RT_TIP_BITS) - 1)) << 8 : 0u;
-                xs[(uint32_t)i * THREADS + tid] = sr[q].x;
+                const uint32_t g = rt_append(live, &sh.n_groups, lane);
+                if (live) {
+                    ent[g] = uint2{((sr[q].y & RT_TIP_MASK) << 8) | w, (sr[q].z & RT_TIP_MASK) << 8};
+                    xs[g] = sr[q].x;
+                }
             }
         }
         {   // |M|, |M_root| (and the statistics) over the workgroup
@@ -313,7 +251,7 @@ __global__ __launch_bounds__(THREADS, RT_MIN_WAVES) void place_regtile_kernel(Db
             }
         }
         __syncthreads();
-        const uint32_t n_m = sh.n_m, n_root = sh.n_root;
+        const uint32_t n_m = sh.n_m, n_root = sh.n_root, n_groups = sh.n_groups;
         auto finish_stats = [&]() {
             if constexpr (STATS) {
                 const uint32_t w = wave_sum(ib);
@@ -334,27 +272,45 @@ __global__ __launch_bounds__(THREADS, RT_MIN_WAVES) void place_regtile_kernel(Db
             if ((uint64_t)n_root < exp_usize) { finish_stats(); record(CLS_UNCLASSIFIABLE_COVERAGE, (int32_t)n_root, 0, 0, 0); continue; }
         }
         // ---- C. descent (place_sequence.rs:279-601) -----------------------------------------------------------------------
-        // Per level: d = |K_a| - |K_b| over the workgroup (a LEAF child is not scored, :322-324: its side counts 0) decides;
-        // then every entry is narrowed to the chosen child and, in the same breath, counted against that child's split.
-        // Both children's node records arrive a level ahead (one 64-byte scalar load per level).
+        // Every thread owns the same entries at every level (j = tid, tid + THREADS, ...): what it lists it settles and
+        // counts itself, no barrier between those.  Both children's node records arrive a level ahead (one 64-byte
+        // scalar load per level).
         snode_pair_t C = load_node_pair(db.nodes, P.s[2]);  // (a binary tree: the root has its two children in consecutive rows)
         if (STATS && tid == 0) ib += 64;
-        int32_t d = P.s[3] ? count_level<SLOTS>(LO, HI, P.s[6] << 8, P.s[3] >= 2 ? 0xFFu : 0u) : 0;
+        // exact share of this thread's settled entries against split a1n: k-mers with a tip before it | at or after it << 16
+        auto count = [&](uint32_t a1ns) {
+            uint32_t da = 0, db_ = 0;
+            for (uint32_t j = tid; j < n_groups; j += THREADS) {
+                const uint2 e = ent[j];
+                const uint32_t w = e.x & 0xFFu;  // (0 for a dead and for a pending entry)
+                da += e.x < a1ns ? w : 0u;
+                db_ += e.y >= a1ns ? w : 0u;
+            }
+            return da | (db_ << 16);
+        };
+        uint32_t dd = P.s[3] ? count(P.s[6] << 8) : 0u;
         int32_t iteration = 0;
+        uint32_t round = 0;  // reductions so far (rotating LDS counters)
         for (;;) {
             ++iteration;
             if (iteration > prm.max_iterations) { record(CLS_ERR_MAX_ITER, 0, 0, (uint32_t)iteration, 0); break; }
-            const uint32_t slot = (uint32_t)iteration % 3u;
-            {
-                const int32_t dw = (int32_t)wave_sum((uint32_t)d);
-                if (lane == 0 && dw) atomicAdd(&sh.cnt[slot], dw);
-            }
-            __syncthreads();
-            const int32_t dt = sh.cnt[slot];
-            if (tid == 0) sh.cnt[(slot + 2) % 3u] = 0;  // (read by everyone before the barrier just passed; next used two levels on)
             const uint32_t m = P.s[3];
             const uint32_t a0 = P.s[0] + 1, a1 = P.s[6];  // first child = [a0, a1), second = [a1, end of the parent)
             const uint32_t a0s = (a0 << 8) | 0xFFu, a1s = a1 << 8;
+            // |K_a| - |K_b| over the workgroup: exact over the settled entries, +- the pending weight
+            auto reduce = [&](uint32_t v_dd, uint32_t v_wp, uint32_t& t_dd, uint32_t& t_wp) {
+                const uint32_t slot = round % 3u;
+                const uint32_t a = wave_sum(v_dd), b = wave_sum(v_wp);
+                if (lane == 0) { if (a) atomicAdd(&sh.cnt[slot][0], a); if (b) atomicAdd(&sh.cnt[slot][1], b); }
+                __syncthreads();
+                t_dd = sh.cnt[slot][0]; t_wp = sh.cnt[slot][1];
+                if (tid < 2) sh.cnt[(slot + 2) % 3u][tid] = 0;  // (read by everyone before the barrier just passed; next used two rounds on)
+                ++round;
+            };
+            auto diff = [&](uint32_t v) { return (int32_t)(m ? (v & 0xFFFFu) : 0u) - (int32_t)(m >= 2 ? (v >> 16) : 0u); };  // a LEAF child is not scored (:322-324)
+            uint32_t t_dd, t_wp;
+            reduce(dd, 0u, t_dd, t_wp);
+            const int32_t dt = diff(t_dd);
             const uint64_t pid = ((uint64_t)P.s[5] << 32) | P.s[4];
             // one_a - rest_a = |only_a| - |only_b| = |K_a| - |K_b| = -(one_b - rest_b) for either remove_intersection:
             // exactly one child passes `one > rest` when the two differ, none on a tie
@@ -369,10 +325,10 @@ __global__ __launch_bounds__(THREADS, RT_MIN_WAVES) void place_regtile_kernel(Db
             for (int i = 0; i < 8; ++i) Pn.s[i] = right ? C.s[8 + i] : C.s[i];
             if (Pn.s[3] == 0) {  // no non-LEAF child below the chosen clade (update_introspection_node.rs:45-85): the record's counts
                 uint32_t ca = 0, cb = 0, bo = 0;
-#pragma unroll
-                for (int i = 0; i < SLOTS; ++i) {
-                    const uint32_t w = LO[i] & 0xFFu;
-                    const bool ina = LO[i] < a1s, inb = HI[i] >= a1s;
+                for (uint32_t j = tid; j < n_groups; j += THREADS) {
+                    const uint2 e = ent[j];
+                    const uint32_t w = e.x & 0xFFu;
+                    const bool ina = e.x < a1s, inb = e.y >= a1s;
                     ca += ina ? w : 0u; cb += inb ? w : 0u; bo += (ina && inb) ? w : 0u;
                 }
                 ca = wave_sum(ca); cb = wave_sum(cb); bo = wave_sum(bo);
@@ -387,72 +343,93 @@ __global__ __launch_bounds__(THREADS, RT_MIN_WAVES) void place_regtile_kernel(Db
             }
             C = load_node_pair(db.nodes, Pn.s[2]);  // its children: looked at after the next barrier
             if (STATS && tid == 0) ib += 64;
-            // narrow every entry to the chosen clade (one 8-byte split half for an entry with tips on both sides of a1)
-            // and count it against the split of that clade's children
-            if (right) narrow_level<true, SLOTS, ADDR32, STATS>(LO, HI, xs + tid, THREADS, half, a0s, a1s, ib);
-            else narrow_level<false, SLOTS, ADDR32, STATS>(LO, HI, xs + tid, THREADS, half, a0s, a1s, ib);
-            d = count_level<SLOTS>(LO, HI, Pn.s[6] << 8, Pn.s[3] >= 2 ? 0xFFu : 0u);
+            // narrow the thread's entries to the chosen clade -- only one with a tip OUTSIDE it is touched: going left one
+            // whose last tip lies at or after a1, going right one whose first tip lies before a1; it dies or, with tips on
+            // both sides, becomes pending on its half -- and count them against the split of that clade's children
+            const uint32_t a1ns = Pn.s[6] << 8;
+            uint32_t da = 0, db_ = 0;
+            for (uint32_t j = tid; j < n_groups; j += THREADS) {
+                uint2 e = ent[j];
+                const bool cnd = right ? e.x < a1s : e.y >= a1s;  // (never a dead entry {MAX, 0})
+                if (cnd) {
+                    // tips on both sides (going left an entry whose first tip is the first child itself dies whatever lies beyond)
+                    const bool str = right ? e.y >= a1s : (e.x < a1s && e.x > a0s);
+                    if (str) {
+#ifndef RT_EXPERIMENT_NO_READS
+                        const uint2 h = ld_half<ADDR32>(half, xs[j], right ? 1u : 0u);
+#else
+                        const uint2 h = uint2{right ? (a1 + 1) : (a0 + 1), 0u};  // (timing experiment: wrong placements)
+#endif
+                        if (STATS) ib += 8;
+                        if (right) { e.x = (h.x << 8) | (e.x & 0xFFu); if (!(e.x > (a1s | 0xFFu))) e = uint2{RT_DEAD_LO, 0u}; }  // the first tip at or after a1; a1 itself: the child is the tip
+                        else e.y = h.x << 8;                                                                                         // the last tip before a1
+                        xs[j] = h.y;
+                    } else e = uint2{RT_DEAD_LO, 0u};
+                    ent[j] = e;
+                }
+                const uint32_t w = e.x & 0xFFu;
+                da += e.x < a1ns ? w : 0u;
+                db_ += e.y >= a1ns ? w : 0u;
+            }
+            dd = da | (db_ << 16);
             P = Pn;
         }
         finish_stats();
     }
 }
 
-// the (threads, slots) instances: 512 x 20 = 10240 lookups (two or three workgroups per CU), 1024 x 20 = 20480
-struct RtShape { uint32_t threads, slots; };
-constexpr RtShape RT_SHAPES[] = {{512, 20}, {1024, 20}};
-
-template <int TH, int SL>
-const void* rt_kernel_of(bool canon, bool stats, bool a32) {
-#define CLS_RT(CN, ST, A) (const void*)place_regtile_kernel<TH, SL, CN, ST, A>
-    if (canon) return stats ? (a32 ? CLS_RT(true, true, true) : CLS_RT(true, true, false)) : (a32 ? CLS_RT(true, false, true) : CLS_RT(true, false, false));
-    return stats ? (a32 ? CLS_RT(false, true, true) : CLS_RT(false, true, false)) : (a32 ? CLS_RT(false, false, true) : CLS_RT(false, false, false));
-#undef CLS_RT
-}
-const void* rt_kernel(uint32_t threads, bool canon, bool stats, bool a32) {
-    return threads == 512 ? rt_kernel_of<512, 20>(canon, stats, a32) : rt_kernel_of<1024, 20>(canon, stats, a32);
+const void* tile_kernel(uint32_t threads, bool canon, bool stats, bool a32) {
+#define CLS_RT3(TH, CN, ST) (a32 ? (const void*)place_tile_kernel<TH, CN, ST, true> : (const void*)place_tile_kernel<TH, CN, ST, false>)
+#define CLS_RT2(TH, CN) (stats ? CLS_RT3(TH, CN, true) : CLS_RT3(TH, CN, false))
+#define CLS_RT1(TH) (canon ? CLS_RT2(TH, true) : CLS_RT2(TH, false))
+    return threads == 512 ? CLS_RT1(512) : CLS_RT1(1024);
+#undef CLS_RT1
+#undef CLS_RT2
+#undef CLS_RT3
 }
 
 }  // namespace
 
-bool regtile_usable(const DbDev& db) {
-    return db.format == FMT_SPLIT && db.binary_tree && db.direct != nullptr && db.n_nodes < (1u << RT_TIP_BITS) - 1 && !tuning().no_tile && !tuning().tile_v1;
+// binary FMT_SPLIT index with a direct table, pre-order indices in 24 bits
+bool tile_usable(const DbDev& db) {
+    return db.format == FMT_SPLIT && db.binary_tree && db.direct != nullptr && db.n_nodes < RT_TIP_MASK && !tuning().no_tile;
 }
 
-RegTilePlan regtile_plan(const DbDev& db, uint32_t want_kmers, uint32_t n_long, uint32_t n_cu, bool stats) {
-    RegTilePlan p{};
+TilePlan tile_plan(const DbDev& db, uint32_t want_kmers, uint32_t n_long, uint32_t n_cu) {
+    TilePlan p{};
     const bool canon = db.canonical != 0;
     const uint32_t want = canon ? want_kmers / 2 : want_kmers;  // lookups of the longest read (canonical: one per window)
-    RtShape shape = RT_SHAPES[sizeof(RT_SHAPES) / sizeof(RT_SHAPES[0]) - 1];
-    for (const RtShape& s : RT_SHAPES) if (s.threads * s.slots >= want) { shape = s; break; }
-    p.threads = shape.threads;
-    p.slots = shape.slots;
-    p.lookups = std::min(want, shape.threads * shape.slots);
-    p.bases = (canon ? p.lookups : p.lookups / 2) + db.k;
-    p.smem = rt_smem(p.bases, p.threads * p.slots);
-    p.cap_kmers = canon ? 2 * p.lookups : p.lookups;
-    const void* kfn = rt_kernel(p.threads, canon, stats, db.addr32 != 0);
-    (void)hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.smem);
-    int per_cu = tuning().tile_blocks_per_cu;
-    if (per_cu <= 0 && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kfn, (int)p.threads, p.smem) != hipSuccess || per_cu <= 0)) per_cu = 1;
-    p.grid = std::max<uint32_t>(1, std::min<uint32_t>(n_long, n_cu * (uint32_t)per_cu));
+    auto bases_of = [&](uint32_t look) { return (canon ? look : look / 2) + db.k; };
+    uint32_t look = want;
+    const size_t lds_max = 160 * 1024 - sizeof(RtSh) - 256;
+    if (rt_smem(look, bases_of(look)) > lds_max) {  // as many lookups per read as 160 KB of LDS hold; longer reads: the workspace kernel
+        look = (uint32_t)((lds_max - 4ull * RT_SET_ENTRIES - 64 - 4ull * 8) / 12);
+        while (look > 64 && rt_smem(look, bases_of(look)) > lds_max) look -= 64;
+    }
+    look = std::min<uint32_t>(look, 32767u);  // weights are summed in 16-bit halves
+    p.lookups = look;
+    p.bases = bases_of(look);
+    p.smem = rt_smem(p.lookups, p.bases);
+    const uint32_t per_cu = (uint32_t)std::min<size_t>(2, (160 * 1024) / (p.smem + sizeof(RtSh) + 256));
+    p.threads = per_cu >= 2 ? 512u : 1024u;
+    p.grid = std::max<uint32_t>(1, std::min<uint32_t>(n_long, n_cu * (p.threads == 512u ? 2u : 1u)));
+    p.cap_kmers = canon ? 2 * look : look;
     return p;
 }
 
-std::string regtile_kernel_name(const DbDev& db, bool stats, uint32_t threads, uint32_t slots) {
+std::string tile_kernel_name(const DbDev& db, bool stats, uint32_t threads) {
     auto b = [](bool v) { return std::string(v ? "true" : "false"); };
-    return "place_regtile_kernel<" + std::to_string(threads) + ", " + std::to_string(slots) + ", " + b(db.canonical != 0) + ", " + b(stats) + ", " + b(db.addr32 != 0) + ">";
+    return "place_tile_kernel<" + std::to_string(threads) + ", " + b(db.canonical != 0) + ", " + b(stats) + ", " + b(db.addr32 != 0) + ">";
 }
 
-void regtile_launch(const DbDev& db, const PlaceParams& prm, const RegTilePlan& p, bool stats, const uint8_t* d_bases, const uint64_t* d_offsets,
-                    const uint32_t* list, const uint32_t* list_len, cls_placement* d_out, cls_query_stats* d_stats, uint32_t* spill_list,
-                    uint32_t* spill_len, hipStream_t stream) {
-    const void* kfn = rt_kernel(p.threads, db.canonical != 0, stats, db.addr32 != 0);
+void tile_launch(const DbDev& db, const PlaceParams& prm, const TilePlan& p, bool stats, const uint8_t* d_bases, const uint64_t* d_offsets,
+                 const uint32_t* list, const uint32_t* list_len, cls_placement* d_out, cls_query_stats* d_stats, uint32_t* spill_list,
+                 uint32_t* spill_len, hipStream_t stream) {
+    const void* kfn = tile_kernel(p.threads, db.canonical != 0, stats, db.addr32 != 0);
     (void)hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.smem);
-    // (the knob counts lookups per pass of a 4096-entry set; this kernel's set has twice the entries)
-    uint32_t max_bases = p.bases, pass_codes = (uint32_t)std::min<long long>(2ll * std::max(1, tuning().tile_pass_codes), 0x7fffffffll);
+    uint32_t max_lookups = p.lookups, max_bases = p.bases, pass_codes = (uint32_t)std::max(1, tuning().tile_pass_codes);
     void* args[] = {(void*)&db, (void*)&prm, (void*)&d_bases, (void*)&d_offsets, (void*)&list, (void*)&list_len, (void*)&d_out, (void*)&d_stats,
-                    (void*)&max_bases, (void*)&pass_codes, (void*)&spill_list, (void*)&spill_len};
+                    (void*)&max_lookups, (void*)&max_bases, (void*)&pass_codes, (void*)&spill_list, (void*)&spill_len};
     (void)hipLaunchKernel(kfn, dim3(p.grid), dim3(p.threads), args, p.smem, stream);
 }
 

@@ -14,8 +14,7 @@ struct Tuning {
     int no_tile = 0;              // CLS_NO_TILE: long reads through the workspace kernel only
     int tile_pass_codes = 1536;   // CLS_TILE_PASS_CODES: lookups per pass of the LDS-tiled kernel's 4096-entry code set (a huge
                                   // value forces one pass, so that long reads overflow the set and take the spill path: tests)
-    int tile_v1 = 0;              // CLS_TILE_V1: the LDS-resident long-read kernel of round 2 instead of the register-tiled one
-    int tile_blocks_per_cu = 0;   // CLS_TILE_BLOCKS_PER_CU: grid of the register-tiled kernel (0: what is resident)
+    int time_class = 0;           // CLS_TIME_CLASS: 2 = cls_db_kernel_time / cls_db_kernel_name follow the workgroup-per-read kernel (reads of 513..4096 + k - 1 bases)
     int blocks_per_cu = 0;        // CLS_BLOCKS_PER_CU: grid of the wave-per-read kernels (0: what is resident)
     int key_blocks_per_cu = 0;    // CLS_KEY_BLOCKS_PER_CU
     int long_blocks_per_cu = 2;   // CLS_LONG_BLOCKS_PER_CU: workspace long-read kernel

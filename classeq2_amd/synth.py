@@ -59,6 +59,10 @@ CONFIGS = {
     # (tree.rs:248-285), and its default is k=35, m=4 (docs/book/02-build-db.md:109-129)
     "C3s12": dict(n_leaves=10_000, ref_len=1500, k_size=12, m_size=4, n_reads=1_000_000, read_len=150, deep=0, max_depth=0,
                   collapse_prob=0.3),
+    # the one workload the reference documents (docs/book/06-telemetry-and-benchmark.md:67-70, fd7/logging.jsonl:2,4): gyrB
+    # queries of ~1.9 kb on a ~590-node support-collapsed tree with its default k=35, m=4 (scaled up to 100 k queries)
+    "G35": dict(n_leaves=300, ref_len=2200, k_size=35, m_size=4, n_reads=100_000, read_len=1900, deep=0, max_depth=0,
+                collapse_prob=0.3),
     "C3s35": dict(n_leaves=10_000, ref_len=1500, k_size=35, m_size=4, n_reads=1_000_000, read_len=150, deep=0, max_depth=0,
                   collapse_prob=0.3),
 }
