@@ -2606,7 +2606,8 @@ hipError_t launch_place(const DbDev& db, const PlaceParams& prm, const PlacePlan
         else CLS_LAUNCH_KEY(false, false);
 #undef CLS_LAUNCH_KEY
 #undef CLS_LAUNCH_KEY_S
-        e = sort_pairs(d_ws + plan.sort_off_words, plan.sort_bytes, keys_in, keys_out, idx_in, idx_out, n_reads, order_key_bits(db), stream);
+        e = sort_pairs(d_ws + plan.sort_off_words, plan.sort_bytes, keys_in, keys_out, idx_in, idx_out, n_reads,
+                       std::min(std::max(0, tuning().order_skip_bits), order_key_bits(db) - 1), order_key_bits(db), stream);
         if (e != hipSuccess) return e;
         list0 = idx_out;
         list0_n = n_reads;

@@ -9,19 +9,21 @@
 //   * a level is DECIDED by the sign of |K_a| - |K_b| (both `remove_intersection` values): one pass
 //     over the entries, two compares each, ONE packed sum per thread, one wave reduction, one barrier; the three counts
 //     of the record are taken once, at the level the descent ends at;
-//   * narrowing touches only an entry with a tip OUTSIDE the chosen child; it dies, or -- tips on both sides -- needs
-//     ONE 8-byte half of its split record (kmers_map.rs:189-203 answered from the split tree).  That read is
-//     ASYNCHRONOUS to the level loop: the entry becomes PENDING (weight parked in HI's low byte, the counts skip it), the
-//     thread keeps the load in flight and goes on.  The next level's counts are exact over the settled entries and
-//     off by at most the pending weight W: with |d| > W the level is decided without the halves (on a ladder nearly
-//     every level: margins are thousands of k-mers, a level's straddlers a few hundred) and they are applied a
-//     level later, long arrived; otherwise the workgroup settles them first and counts again.
+//   * narrowing touches only an entry with a tip OUTSIDE the chosen child: it dies, or -- tips on both sides -- reads
+//     ONE 8-byte half of its split record (kmers_map.rs:189-203 answered from the split tree); every other entry costs
+//     one LDS read and three compares a level.
+// (Measured and rejected, round 3: the entries in registers, 20 per thread of a 512-thread workgroup, two workgroups per
+// CU -- the unrolled per-slot code costs more instructions than the second workgroup hides; halves read asynchronously
+// and applied a level later, the level decided early when |K_a| - |K_b| exceeds the weight still in flight -- it hides
+// the reads (a build that skips them runs within 10 %) but needs a register per entry slot for the loads, and the
+// unrolled loop that comes with it is slower than this rolled one.  DESIGN.md 6.)
 // A read whose codes overflow a partition of the set (adversarial input only) goes to the workspace kernel through
 // the spill list.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
 #include <string>
+#include <type_traits>
 
 #include "cls_device.h"
 #include "cls_devutil.h"
@@ -43,7 +45,7 @@ constexpr uint32_t RT_SET_EMPTY = 0xFFFFFFFFu;
 constexpr int RT_LOOK = RT_LOOK_N;          // table lookups / set records a thread keeps in flight
 
 struct RtSh {
-    uint32_t cnt[3][2];      // rotating per-round sums {k-mers with a tip before the split | at or after it << 16, pending weight}
+    uint32_t cnt[3];         // rotating per-level sums: k-mers with a tip before the split | at or after it << 16
     uint32_t fin[3];         // the three counts of the final level
     uint32_t n_groups;
     uint32_t n_m, n_root;
@@ -79,7 +81,7 @@ __global__ __launch_bounds__(THREADS) void place_tile_kernel(DbDev db, PlacePara
     __shared__ RtSh sh;
     uint32_t* const packed = reinterpret_cast<uint32_t*>(smem);
     uint32_t* const cset = packed + rt_packed_words(max_bases);
-    uint2* const ent = reinterpret_cast<uint2*>(cset + RT_SET_ENTRIES);            // {LO = first tip << 8 | weight, HI = last tip << 8 | pending weight}
+    uint2* const ent = reinterpret_cast<uint2*>(cset + RT_SET_ENTRIES);            // {LO = first tip << 8 | weight, HI = last tip << 8}; dead: {RT_DEAD_LO, 0}
     uint32_t* const xs = reinterpret_cast<uint32_t*>(ent + max_lookups);           // split record of the entry's set
     uint32_t* const wsid = xs;  // front only: per window its tip-set id | bit 31 (the lookup stands for ONE k-mer) if it is the first with its code, else 0
     const uint32_t tid = threadIdx.x, lane = tid & 63;
@@ -133,8 +135,7 @@ __global__ __launch_bounds__(THREADS) void place_tile_kernel(DbDev db, PlacePara
             packed[w] = acc;
         }
         if (tid == 0) { sh.n_groups = 0; sh.n_m = 0; sh.n_root = 0; sh.overflow = 0; sh.ib = 0; sh.leafp = 0; }
-        if (tid < 6) (&sh.cnt[0][0])[tid] = 0;
-        if (tid < 3) sh.fin[tid] = 0;
+        if (tid < 3) { sh.cnt[tid] = 0; sh.fin[tid] = 0; }
         if (__syncthreads_or(bad ? 1 : 0)) { put_stats(0, 0, 0, 0, 0); record(CLS_ERR_INVALID_BASE, 0, 0, 0, 0); continue; }
         // code (and palindrome flag) of lookup j: forward windows first, then those of the reverse complement (kmers_map.rs:387-395)
         auto code_of = [&](uint32_t j, bool& palindrome) -> uint32_t {
@@ -290,27 +291,22 @@ __global__ __launch_bounds__(THREADS) void place_tile_kernel(DbDev db, PlacePara
         };
         uint32_t dd = P.s[3] ? count(P.s[6] << 8) : 0u;
         int32_t iteration = 0;
-        uint32_t round = 0;  // reductions so far (rotating LDS counters)
         for (;;) {
             ++iteration;
             if (iteration > prm.max_iterations) { record(CLS_ERR_MAX_ITER, 0, 0, (uint32_t)iteration, 0); break; }
             const uint32_t m = P.s[3];
             const uint32_t a0 = P.s[0] + 1, a1 = P.s[6];  // first child = [a0, a1), second = [a1, end of the parent)
             const uint32_t a0s = (a0 << 8) | 0xFFu, a1s = a1 << 8;
-            // |K_a| - |K_b| over the workgroup: exact over the settled entries, +- the pending weight
-            auto reduce = [&](uint32_t v_dd, uint32_t v_wp, uint32_t& t_dd, uint32_t& t_wp) {
-                const uint32_t slot = round % 3u;
-                const uint32_t a = wave_sum(v_dd), b = wave_sum(v_wp);
-                if (lane == 0) { if (a) atomicAdd(&sh.cnt[slot][0], a); if (b) atomicAdd(&sh.cnt[slot][1], b); }
-                __syncthreads();
-                t_dd = sh.cnt[slot][0]; t_wp = sh.cnt[slot][1];
-                if (tid < 2) sh.cnt[(slot + 2) % 3u][tid] = 0;  // (read by everyone before the barrier just passed; next used two rounds on)
-                ++round;
-            };
-            auto diff = [&](uint32_t v) { return (int32_t)(m ? (v & 0xFFFFu) : 0u) - (int32_t)(m >= 2 ? (v >> 16) : 0u); };  // a LEAF child is not scored (:322-324)
-            uint32_t t_dd, t_wp;
-            reduce(dd, 0u, t_dd, t_wp);
-            const int32_t dt = diff(t_dd);
+            // |K_a| - |K_b| over the workgroup (a LEAF child is not scored, :322-324)
+            const uint32_t slot = (uint32_t)iteration % 3u;
+            {
+                const uint32_t a = wave_sum(dd);
+                if (lane == 0 && a) atomicAdd(&sh.cnt[slot], a);
+            }
+            __syncthreads();
+            const uint32_t t_dd = sh.cnt[slot];
+            if (tid == 0) sh.cnt[(slot + 2) % 3u] = 0;  // (read by everyone before the barrier just passed; next used two levels on)
+            const int32_t dt = (int32_t)(m ? (t_dd & 0xFFFFu) : 0u) - (int32_t)(m >= 2 ? (t_dd >> 16) : 0u);
             const uint64_t pid = ((uint64_t)P.s[5] << 32) | P.s[4];
             // one_a - rest_a = |only_a| - |only_b| = |K_a| - |K_b| = -(one_b - rest_b) for either remove_intersection:
             // exactly one child passes `one > rest` when the two differ, none on a tie
@@ -348,29 +344,32 @@ __global__ __launch_bounds__(THREADS) void place_tile_kernel(DbDev db, PlacePara
             // both sides, becomes pending on its half -- and count them against the split of that clade's children
             const uint32_t a1ns = Pn.s[6] << 8;
             uint32_t da = 0, db_ = 0;
-            for (uint32_t j = tid; j < n_groups; j += THREADS) {
-                uint2 e = ent[j];
-                const bool cnd = right ? e.x < a1s : e.y >= a1s;  // (never a dead entry {MAX, 0})
-                if (cnd) {
-                    // tips on both sides (going left an entry whose first tip is the first child itself dies whatever lies beyond)
-                    const bool str = right ? e.y >= a1s : (e.x < a1s && e.x > a0s);
-                    if (str) {
+            auto narrow = [&](auto right_c) {
+                constexpr bool RIGHT = decltype(right_c)::value;
+                for (uint32_t j = tid; j < n_groups; j += THREADS) {
+                    uint2 e = ent[j];
+                    if (RIGHT ? e.x < a1s : e.y >= a1s) {  // (never a dead entry {MAX, 0})
+                        // tips on both sides (going left an entry whose first tip is the first child itself dies whatever lies beyond)
+                        const bool str = RIGHT ? e.y >= a1s : (e.x < a1s && e.x > a0s);
+                        if (str) {
 #ifndef RT_EXPERIMENT_NO_READS
-                        const uint2 h = ld_half<ADDR32>(half, xs[j], right ? 1u : 0u);
+                            const uint2 h = ld_half<ADDR32>(half, xs[j], RIGHT ? 1u : 0u);
 #else
-                        const uint2 h = uint2{right ? (a1 + 1) : (a0 + 1), 0u};  // (timing experiment: wrong placements)
+                            const uint2 h = uint2{RIGHT ? (a1 + 1) : (a0 + 1), 0u};  // (timing experiment: wrong placements)
 #endif
-                        if (STATS) ib += 8;
-                        if (right) { e.x = (h.x << 8) | (e.x & 0xFFu); if (!(e.x > (a1s | 0xFFu))) e = uint2{RT_DEAD_LO, 0u}; }  // the first tip at or after a1; a1 itself: the child is the tip
-                        else e.y = h.x << 8;                                                                                         // the last tip before a1
-                        xs[j] = h.y;
-                    } else e = uint2{RT_DEAD_LO, 0u};
-                    ent[j] = e;
+                            if (STATS) ib += 8;
+                            if (RIGHT) { e.x = (h.x << 8) | (e.x & 0xFFu); if (!(e.x > (a1s | 0xFFu))) e = uint2{RT_DEAD_LO, 0u}; }  // the first tip at or after a1; a1 itself: the child is the tip
+                            else e.y = h.x << 8;                                                                                         // the last tip before a1
+                            xs[j] = h.y;
+                        } else e = uint2{RT_DEAD_LO, 0u};
+                        ent[j] = e;
+                    }
+                    const uint32_t w = e.x & 0xFFu;
+                    da += e.x < a1ns ? w : 0u;
+                    db_ += e.y >= a1ns ? w : 0u;
                 }
-                const uint32_t w = e.x & 0xFFu;
-                da += e.x < a1ns ? w : 0u;
-                db_ += e.y >= a1ns ? w : 0u;
-            }
+            };
+            if (right) narrow(std::true_type{}); else narrow(std::false_type{});
             dd = da | (db_ << 16);
             P = Pn;
         }

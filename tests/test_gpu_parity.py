@@ -3,7 +3,7 @@ import numpy as np
 import pytest
 
 from classeq2_amd import _abi, engine
-from classeq2_amd.synth import SynthDb
+from classeq2_amd.synth import CONFIGS, SynthDb
 from oracle import oracle_port as op
 from tests.helpers import (ODD_PARAM_SETS, PARAM_SETS, describe, drop_random_nodes, ragged_reads, records_equal, stats_equal,
                            truncate_random_sets)
@@ -401,3 +401,15 @@ def test_mask_halves_on_and_off_agree(k, deep, trunc, collapse):
             _check(flat, bases, offsets, kw, threads=16)
     finally:
         engine.set_tuning("no_mask_halves", 0)
+
+
+def test_g35_the_references_documented_workload_shape():
+    """bench.py --config G35 at test size: the one workload the reference documents (docs/book/06-telemetry-and-benchmark.md:67-70,
+    fd7/logging.jsonl:2,4) -- ~1.9 kb queries, a ~590-node support-collapsed tree, k=35, m=4 -- through the
+    workgroup-per-read kernel, both remove_intersection values, against the oracle."""
+    cfg = CONFIGS["G35"]
+    s = SynthDb(cfg["n_leaves"], cfg["ref_len"], cfg["k_size"], cfg["m_size"], collapse_prob=cfg["collapse_prob"])
+    bases, offsets, _ = s.reads(600, cfg["read_len"], seed=3)
+    for kw in (dict(), dict(remove_intersection=True)):
+        got = _check(s.flat, bases, offsets, kw, threads=16)
+    assert (got["status"] == _abi.IDENTITY_FOUND).sum() + (got["status"] == _abi.MAX_RESOLUTION).sum() > 500
