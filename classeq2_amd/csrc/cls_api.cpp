@@ -119,7 +119,7 @@ namespace {
 struct Knob { const char* name; int cls::Tuning::*field; };
 const Knob KNOBS[] = {
     {"no_fast", &cls::Tuning::no_fast}, {"no_order", &cls::Tuning::no_order}, {"force_list", &cls::Tuning::force_list},
-    {"no_mask_halves", &cls::Tuning::no_mask_halves}, {"no_fat_direct", &cls::Tuning::no_fat_direct}, {"no_tile", &cls::Tuning::no_tile}, {"tile_pass_codes", &cls::Tuning::tile_pass_codes}, {"time_class", &cls::Tuning::time_class}, {"order_skip_bits", &cls::Tuning::order_skip_bits}, {"blocks_per_cu", &cls::Tuning::blocks_per_cu}, {"key_blocks_per_cu", &cls::Tuning::key_blocks_per_cu},
+    {"no_mask_halves", &cls::Tuning::no_mask_halves}, {"no_fat_direct", &cls::Tuning::no_fat_direct}, {"no_tile", &cls::Tuning::no_tile}, {"tile_pass_codes", &cls::Tuning::tile_pass_codes}, {"time_class", &cls::Tuning::time_class}, {"blocks_per_cu", &cls::Tuning::blocks_per_cu}, {"key_blocks_per_cu", &cls::Tuning::key_blocks_per_cu},
     {"long_blocks_per_cu", &cls::Tuning::long_blocks_per_cu}, {"order_mode", &cls::Tuning::order_mode},
     {"order_windows", &cls::Tuning::order_windows}, {"order_both_strands", &cls::Tuning::order_both_strands},
     {"order_block_shift", &cls::Tuning::order_block_shift}, {"order_sample_shift", &cls::Tuning::order_sample_shift},
@@ -300,6 +300,15 @@ extern "C" int cls_db_info_get(const cls_db* db, cls_db_info* info) {
     return CLS_OK;
 }
 
+extern "C" int cls_db_info_get2(const cls_db* db, void* info, size_t info_size) {
+    if (!db || !info) return fail(CLS_E_INVALID_ARG, "cls_db_info_get2: null argument");
+    cls_db_info full;
+    const int rc = cls_db_info_get(db, &full);
+    if (rc != CLS_OK) return rc;
+    memcpy(info, &full, info_size < sizeof(full) ? info_size : sizeof(full));
+    return CLS_OK;
+}
+
 // fold finished kernel timings into the handle's accumulators (ws_mu held); `wait`: also those still running
 static void harvest(cls_db* db, bool wait) {
     for (auto& t : db->timed) {
@@ -339,7 +348,8 @@ static int acquire_ws(cls_db* db, uint64_t words, hipStream_t stream, size_t* sl
         for (size_t i = 0; i < db->ws.size(); ++i) {
             Workspace& w = db->ws[i];
             if (w.busy && w.recorded && w.launching == 0 && hipEventQuery(w.done) == hipSuccess) w.busy = false;
-            const bool same_stream = w.busy && w.recorded && w.launching == 0 && w.stream == stream;
+            // (hipStreamPerThread is ONE handle value that names a different stream in every host thread: never a "same stream")
+            const bool same_stream = w.busy && w.recorded && w.launching == 0 && w.stream == stream && stream != hipStreamPerThread;
             if ((!w.busy || same_stream) && w.words >= words) {
                 w.busy = true; w.recorded = false; w.launching = 1; w.stream = stream; w.seq = ++db->ws_seq;
                 *slot = i; *use = w;

@@ -2514,7 +2514,7 @@ PlacePlan plan_place(const DbDev& db, uint32_t n_reads, uint32_t n_cu, bool stat
         p.keys_off_words = w;
         w += 6 * (uint64_t)n_reads;
         p.sort_off_words = w;
-        p.sort_bytes = sort_temp_bytes(n_reads, ORDER_KEY_BITS_MAX + 5);
+        p.sort_bytes = order_temp_bytes();
         w += (p.sort_bytes + 3) / 4 + 2;
         w += w & 1;
     }
@@ -2606,8 +2606,7 @@ hipError_t launch_place(const DbDev& db, const PlaceParams& prm, const PlacePlan
         else CLS_LAUNCH_KEY(false, false);
 #undef CLS_LAUNCH_KEY
 #undef CLS_LAUNCH_KEY_S
-        e = sort_pairs(d_ws + plan.sort_off_words, plan.sort_bytes, keys_in, keys_out, idx_in, idx_out, n_reads,
-                       std::min(std::max(0, tuning().order_skip_bits), order_key_bits(db) - 1), order_key_bits(db), stream);
+        e = order_reads(d_ws + plan.sort_off_words, keys_in, idx_out, n_reads, order_key_bits(db) - 1, stream);  // (- 1: the bit that only the all-ones "no key" sets)
         if (e != hipSuccess) return e;
         list0 = idx_out;
         list0_n = n_reads;

@@ -4,7 +4,10 @@
 #include <stdint.h>
 
 namespace cls {
-size_t sort_temp_bytes(uint32_t n, int end_bit);
-hipError_t sort_pairs(void* tmp, size_t tmp_bytes, const uint64_t* keys_in, uint64_t* keys_out, const uint32_t* vals_in,
-                      uint32_t* vals_out, uint32_t n, int begin_bit, int end_bit, hipStream_t stream);
+constexpr int ORDER_BIN_BITS = 12;                 // top bits of the locality key the reads are binned by
+constexpr uint32_t ORDER_BINS = 1u << ORDER_BIN_BITS;
+size_t order_temp_bytes();
+// idx_out = the reads 0 .. n-1 ordered by the top ORDER_BIN_BITS of their `key_bits`-bit keys (all-ones key: last);
+// `tmp` holds order_temp_bytes(); asynchronous on `stream`.
+hipError_t order_reads(void* tmp, const uint64_t* keys, uint32_t* idx_out, uint32_t n, int key_bits, hipStream_t stream);
 }  // namespace cls

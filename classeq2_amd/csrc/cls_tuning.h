@@ -22,7 +22,6 @@ struct Tuning {
     int order_windows = 64;       // CLS_ORDER_WINDOWS: windows of a read that make its locality key
     int order_both_strands = 0;   // CLS_ORDER_BOTH_STRANDS
     int order_block_shift = 2;    // CLS_ORDER_BLOCK_SHIFT
-    int order_skip_bits = 0;      // CLS_ORDER_SKIP_BITS: low bits of the locality key the sort ignores (experiment: how much of the key the order needs)
     int order_sample_shift = 32;  // CLS_ORDER_SAMPLE_SHIFT
     int profile_stop = 0;         // CLS_PROFILE_STOP (needs a -DCLS_PROFILE_HOOKS build)
     int timing = 0;               // CLS_TIMING: phase times of cls_place_sequences on stderr

@@ -22,7 +22,7 @@ LIB_PATH = os.environ.get("CLS_PLACE_LIB") or os.path.join(_HERE, "csrc", "libcl
 _LIB = None
 
 EXPORTS = [
-    "cls_device_count", "cls_db_create", "cls_db_validate", "cls_db_destroy", "cls_db_info_get", "cls_db_kernel_time", "cls_db_kernel_name",
+    "cls_device_count", "cls_db_create", "cls_db_validate", "cls_db_destroy", "cls_db_info_get", "cls_db_info_get2", "cls_db_kernel_time", "cls_db_kernel_name",
     "cls_db_set_max_read_len", "cls_place_batch",
     "cls_place_batch_device", "cls_place_batch_stats", "cls_fasta_parse", "cls_fasta_free", "cls_fasta_scan_device", "cls_fasta_dev_free",
     "cls_fasta_parse_gpu", "cls_place_fasta_text", "cls_last_error",

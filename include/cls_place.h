@@ -208,6 +208,10 @@ int cls_db_create(const cls_db_desc* d, int device, cls_db** out);
 int cls_db_validate(const cls_db_desc* d);
 void cls_db_destroy(cls_db* db);
 int cls_db_info_get(const cls_db* db, cls_db_info* info);
+/* The same for a caller compiled against an OLDER header: copies the first min(info_size, sizeof(cls_db_info))
+ * bytes.  The struct only ever grows at its end (88 bytes in round 1, 96 since `fat_direct_table`): a binding that
+ * may meet a newer library passes its own sizeof and never has bytes written past its struct. */
+int cls_db_info_get2(const cls_db* db, void* info, size_t info_size);
 
 /* Place `n` queries.  `bases` holds the concatenated sequences exactly as
  * `SequenceBody` holds them when place_sequence receives them (after the
