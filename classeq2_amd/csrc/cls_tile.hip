@@ -3,7 +3,7 @@
 //
 // The algorithm is place_sequence.rs:42-601 as in cls_kernels.hip (A: k-mers + lookup + distinct hashes,
 // B: thresholds, C: descent).  Layout: the read packed 2 bits per base, a set of codes that makes the k-mers distinct
-// (filled in PASSES over hash partitions of the codes: a read of any length), and one ENTRY per run of consecutive
+// (over the entries' space, which it precedes in time), and one ENTRY per run of consecutive
 // windows that share a tip set: {first tip << 8 | weight, last tip << 8} + the set's split record, 12 bytes of LDS.
 // What the descent is built around (on a 150-level ladder tree a level costs what its dependent chain costs):
 //   * a level is DECIDED by the sign of |K_a| - |K_b| (both `remove_intersection` values): one pass
@@ -34,7 +34,6 @@ namespace cls {
 
 namespace {
 
-constexpr uint32_t RT_SET_ENTRIES = 4096;   // LDS set of codes per pass (16 KB)
 constexpr uint32_t RT_TIP_BITS = 24;        // pre-order indices an entry holds (tip << 8 | weight)
 constexpr uint32_t RT_TIP_MASK = (1u << RT_TIP_BITS) - 1;
 constexpr uint32_t RT_DEAD_LO = 0xFFFFFF00u;
@@ -57,7 +56,7 @@ struct RtSh {
 __host__ __device__ inline uint32_t rt_packed_words(uint32_t max_bases) { return ((max_bases + 15) / 16 + 2 + 3) & ~3u; }
 // dynamic LDS for reads of up to `max_lookups` table lookups and `max_bases` bases
 __host__ __device__ inline size_t rt_smem(uint32_t max_lookups, uint32_t max_bases) {
-    return 4ull * rt_packed_words(max_bases) + 4ull * RT_SET_ENTRIES + 8ull * max_lookups + 4ull * max_lookups + 16;
+    return 4ull * rt_packed_words(max_bases) + 8ull * max_lookups + 4ull * max_lookups + 16;
 }
 
 // position of this thread's element in a list that all threads of the workgroup append to (wave-aggregated)
@@ -76,12 +75,13 @@ __global__ __launch_bounds__(THREADS) void place_tile_kernel(DbDev db, PlacePara
                                                              const uint64_t* __restrict__ offsets, const uint32_t* __restrict__ list,
                                                              const uint32_t* __restrict__ list_len, cls_placement* __restrict__ out,
                                                              cls_query_stats* __restrict__ stats, uint32_t max_lookups, uint32_t max_bases,
-                                                             uint32_t pass_codes, uint32_t* __restrict__ spill_list, uint32_t* __restrict__ spill_len) {
+                                                             uint32_t pass_codes, uint32_t set_words, uint32_t* __restrict__ spill_list, uint32_t* __restrict__ spill_len) {
     extern __shared__ __align__(16) uint8_t smem[];
     __shared__ RtSh sh;
     uint32_t* const packed = reinterpret_cast<uint32_t*>(smem);
-    uint32_t* const cset = packed + rt_packed_words(max_bases);
-    uint2* const ent = reinterpret_cast<uint2*>(cset + RT_SET_ENTRIES);            // {LO = first tip << 8 | weight, HI = last tip << 8}; dead: {RT_DEAD_LO, 0}
+    uint2* const ent = reinterpret_cast<uint2*>(packed + rt_packed_words(max_bases));
+    uint32_t* const cset = reinterpret_cast<uint32_t*>(ent);  // front only: the set of codes that makes the k-mers distinct lies over the
+                                                              // entries (made after it is done): 2 * max_lookups words, one pass at load <= 0.5            // {LO = first tip << 8 | weight, HI = last tip << 8}; dead: {RT_DEAD_LO, 0}
     uint32_t* const xs = reinterpret_cast<uint32_t*>(ent + max_lookups);           // split record of the entry's set
     uint32_t* const wsid = xs;  // front only: per window its tip-set id | bit 31 (the lookup stands for ONE k-mer) if it is the first with its code, else 0
     const uint32_t tid = threadIdx.x, lane = tid & 63;
@@ -169,25 +169,27 @@ __global__ __launch_bounds__(THREADS) void place_tile_kernel(DbDev db, PlacePara
             }
         }
         // ---- A2a'. distinct k-mers (HashSet<u64> of hashes, kmers_map.rs:273-311): the codes that are in the index go
-        // through an LDS set, in passes over hash partitions of the codes; a later window with the same code drops out
+        // through an LDS set (ONE pass: the set has two words per possible lookup; `pass_codes` / `set_words` below their
+        // defaults make it passes over hash partitions of the codes, and a partition that does not fit spills the read:
+        // tests); a later window with the same code drops out
         // (a thread only ever touches its own words of wsid: no barrier between the lookups and the passes) ----
         const uint32_t n_pass = (n_look + pass_codes - 1) / pass_codes;
         for (uint32_t pass = 0; pass < n_pass; ++pass) {
             if (pass) __syncthreads();  // the previous pass' set is no longer probed
-            for (uint32_t i = tid; i < RT_SET_ENTRIES; i += THREADS) cset[i] = RT_SET_EMPTY;
+            for (uint32_t i = tid; i < set_words; i += THREADS) cset[i] = RT_SET_EMPTY;
             __syncthreads();
             for (uint32_t j = tid; j < n_look; j += THREADS) {
                 if (wsid[j] == 0) continue;
                 bool palindrome;
                 const uint32_t code = code_of(j, palindrome);
                 if (n_pass != 1 && (uint32_t)(((uint64_t)mix32(code) * n_pass) >> 32) != pass) continue;
-                uint32_t pos = (code * 2654435761u) & (RT_SET_ENTRIES - 1);
+                uint32_t pos = (uint32_t)(((uint64_t)(code * 2654435761u) * set_words) >> 32);
                 for (uint32_t probes = 0;; ++probes) {
-                    if (probes == RT_SET_ENTRIES) { sh.overflow = 1; wsid[j] = 0; break; }  // (a partition that does not fit: spill the read)
+                    if (probes == set_words) { sh.overflow = 1; wsid[j] = 0; break; }  // (a partition that does not fit: spill the read)
                     const uint32_t old = atomicCAS(&cset[pos], RT_SET_EMPTY, code);
                     if (old == RT_SET_EMPTY) break;
                     if (old == code) { wsid[j] = 0; break; }
-                    pos = (pos + 1) & (RT_SET_ENTRIES - 1);
+                    pos = pos + 1 == set_words ? 0u : pos + 1;
                 }
             }
         }
@@ -346,27 +348,33 @@ __global__ __launch_bounds__(THREADS) void place_tile_kernel(DbDev db, PlacePara
             uint32_t da = 0, db_ = 0;
             auto narrow = [&](auto right_c) {
                 constexpr bool RIGHT = decltype(right_c)::value;
-                for (uint32_t j = tid; j < n_groups; j += THREADS) {
-                    uint2 e = ent[j];
-                    if (RIGHT ? e.x < a1s : e.y >= a1s) {  // (never a dead entry {MAX, 0})
-                        // tips on both sides (going left an entry whose first tip is the first child itself dies whatever lies beyond)
-                        const bool str = RIGHT ? e.y >= a1s : (e.x < a1s && e.x > a0s);
-                        if (str) {
+                // an entry with a tip outside the child taken (or whose first tip IS that child: it has nothing below it)
+                auto outside = [&](const uint2& e) { return RIGHT ? e.x <= (a1s | 0xFFu) : (e.y >= a1s || e.x <= a0s); };
+                auto fix = [&](uint2& e, uint32_t j) {  // the rare path: such an entry dies or takes the half of its split record
+                    if (!outside(e)) return;
+                    const bool str = e.x < a1s && e.y >= a1s && (RIGHT || e.x > a0s);  // tips on both sides
+                    if (str) {
 #ifndef RT_EXPERIMENT_NO_READS
-                            const uint2 h = ld_half<ADDR32>(half, xs[j], RIGHT ? 1u : 0u);
+                        const uint2 h = ld_half<ADDR32>(half, xs[j], RIGHT ? 1u : 0u);
 #else
-                            const uint2 h = uint2{RIGHT ? (a1 + 1) : (a0 + 1), 0u};  // (timing experiment: wrong placements)
+                        const uint2 h = uint2{RIGHT ? (a1 + 1) : (a0 + 1), 0u};  // (timing experiment: wrong placements)
 #endif
-                            if (STATS) ib += 8;
-                            if (RIGHT) { e.x = (h.x << 8) | (e.x & 0xFFu); if (!(e.x > (a1s | 0xFFu))) e = uint2{RT_DEAD_LO, 0u}; }  // the first tip at or after a1; a1 itself: the child is the tip
-                            else e.y = h.x << 8;                                                                                         // the last tip before a1
-                            xs[j] = h.y;
-                        } else e = uint2{RT_DEAD_LO, 0u};
-                        ent[j] = e;
-                    }
+                        if (STATS) ib += 8;
+                        if (RIGHT) { e.x = (h.x << 8) | (e.x & 0xFFu); if (!(e.x > (a1s | 0xFFu))) e = uint2{RT_DEAD_LO, 0u}; }  // the first tip at or after a1; a1 itself: the child is the tip
+                        else e.y = h.x << 8;                                                                                         // the last tip before a1
+                        xs[j] = h.y;
+                    } else e = uint2{RT_DEAD_LO, 0u};
+                    ent[j] = e;
+                };
+                auto tally = [&](const uint2& e) {
                     const uint32_t w = e.x & 0xFFu;
                     da += e.x < a1ns ? w : 0u;
                     db_ += e.y >= a1ns ? w : 0u;
+                };
+                for (uint32_t j = tid; j < n_groups; j += THREADS) {
+                    uint2 e = ent[j];
+                    fix(e, j);
+                    tally(e);
                 }
             };
             if (right) narrow(std::true_type{}); else narrow(std::false_type{});
@@ -402,7 +410,7 @@ TilePlan tile_plan(const DbDev& db, uint32_t want_kmers, uint32_t n_long, uint32
     uint32_t look = want;
     const size_t lds_max = 160 * 1024 - sizeof(RtSh) - 256;
     if (rt_smem(look, bases_of(look)) > lds_max) {  // as many lookups per read as 160 KB of LDS hold; longer reads: the workspace kernel
-        look = (uint32_t)((lds_max - 4ull * RT_SET_ENTRIES - 64 - 4ull * 8) / 12);
+        look = (uint32_t)((lds_max - 64 - 4ull * 8) / 12);
         while (look > 64 && rt_smem(look, bases_of(look)) > lds_max) look -= 64;
     }
     look = std::min<uint32_t>(look, 32767u);  // weights are summed in 16-bit halves
@@ -426,9 +434,13 @@ void tile_launch(const DbDev& db, const PlaceParams& prm, const TilePlan& p, boo
                  uint32_t* spill_len, hipStream_t stream) {
     const void* kfn = tile_kernel(p.threads, db.canonical != 0, stats, db.addr32 != 0);
     (void)hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.smem);
-    uint32_t max_lookups = p.lookups, max_bases = p.bases, pass_codes = (uint32_t)std::max(1, tuning().tile_pass_codes);
+    // the code set: two words per lookup the LDS is provisioned for, every code in one pass (knobs: fewer words / codes per pass)
+    uint32_t max_lookups = p.lookups, max_bases = p.bases;
+    uint32_t set_words = 2 * p.lookups, pass_codes = p.lookups;
+    if (tuning().tile_set_words > 0) set_words = std::min<uint32_t>(set_words, (uint32_t)tuning().tile_set_words);
+    if (tuning().tile_pass_codes > 0) pass_codes = (uint32_t)tuning().tile_pass_codes;
     void* args[] = {(void*)&db, (void*)&prm, (void*)&d_bases, (void*)&d_offsets, (void*)&list, (void*)&list_len, (void*)&d_out, (void*)&d_stats,
-                    (void*)&max_lookups, (void*)&max_bases, (void*)&pass_codes, (void*)&spill_list, (void*)&spill_len};
+                    (void*)&max_lookups, (void*)&max_bases, (void*)&pass_codes, (void*)&set_words, (void*)&spill_list, (void*)&spill_len};
     (void)hipLaunchKernel(kfn, dim3(p.grid), dim3(p.threads), args, p.smem, stream);
 }
 

@@ -12,8 +12,9 @@ struct Tuning {
     int no_mask_halves = 0;       // CLS_NO_MASK_HALVES: no second copy of the split records with narrow parts as bit masks (set before cls_db_create)
     int no_fat_direct = 0;        // CLS_NO_FAT_DIRECT: no denormalised 16-byte direct table for k <= 12 (set before cls_db_create)
     int no_tile = 0;              // CLS_NO_TILE: long reads through the workspace kernel only
-    int tile_pass_codes = 1536;   // CLS_TILE_PASS_CODES: lookups per pass of the LDS-tiled kernel's 4096-entry code set (a huge
-                                  // value forces one pass, so that long reads overflow the set and take the spill path: tests)
+    int tile_pass_codes = 0;      // CLS_TILE_PASS_CODES: lookups per pass of the LDS-tiled kernel's code set (0: all of a read's in one pass)
+    int tile_set_words = 0;       // CLS_TILE_SET_WORDS: words of that set (0: two per lookup; a small set with one pass overflows on a
+                                  // long read, which then takes the spill path: tests)
     int time_class = 0;           // CLS_TIME_CLASS: 2 = cls_db_kernel_time / cls_db_kernel_name follow the workgroup-per-read kernel (reads of 513..4096 + k - 1 bases)
     int blocks_per_cu = 0;        // CLS_BLOCKS_PER_CU: grid of the wave-per-read kernels (0: what is resident)
     int key_blocks_per_cu = 0;    // CLS_KEY_BLOCKS_PER_CU

@@ -338,12 +338,15 @@ def test_long_reads_lds_tiled_kernel_and_its_spill_path():
             got = _check(flat, bases, offsets, kw, threads=16)
             want[(tag, tuple(kw))] = got
         assert (got["status"] != _abi.ERR_READ_TOO_LONG).all()
-    engine.set_tuning("tile_pass_codes", 1 << 30)
-    try:
-        got = _check(s.flat, bases, offsets, {}, threads=16)
-        assert len(records_equal(got, want[("sym", ())])) == 0
-    finally:
-        engine.set_tuning("tile_pass_codes", 1536)
+    for pass_codes, set_words in ((1 << 30, 4096), (1024, 4096)):  # one pass into a small set: long reads overflow it and spill; passes over hash partitions
+        engine.set_tuning("tile_pass_codes", pass_codes)
+        engine.set_tuning("tile_set_words", set_words)
+        try:
+            got = _check(s.flat, bases, offsets, {}, threads=16)
+            assert len(records_equal(got, want[("sym", ())])) == 0
+        finally:
+            engine.set_tuning("tile_pass_codes", 0)
+            engine.set_tuning("tile_set_words", 0)
     engine.set_tuning("no_tile", 1)
     try:
         got = _check(s.flat, bases, offsets, {}, threads=16)
