@@ -2514,7 +2514,7 @@ PlacePlan plan_place(const DbDev& db, uint32_t n_reads, uint32_t n_cu, bool stat
         p.keys_off_words = w;
         w += 6 * (uint64_t)n_reads;
         p.sort_off_words = w;
-        p.sort_bytes = order_temp_bytes();
+        p.sort_bytes = order_temp_bytes(n_reads);
         w += (p.sort_bytes + 3) / 4 + 2;
         w += w & 1;
     }

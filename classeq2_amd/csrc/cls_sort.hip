@@ -13,14 +13,16 @@ namespace cls {
 
 namespace {
 
-constexpr int SORT_THREADS = 256, SORT_PER_THREAD = 16;
+constexpr int SORT_THREADS = 1024, SORT_PER_THREAD = 16;  // 16384 reads a workgroup: nearly every bin occurs in it, ONE global atomic per bin
 
 __device__ __forceinline__ uint32_t bin_of(uint64_t key, int shift) {
     return key == ~0ull ? ORDER_BINS - 1 : (uint32_t)(key >> shift) & (ORDER_BINS - 1);  // (reads without a key: the last bin)
 }
 
-// per workgroup a histogram in LDS, flushed with one global atomic per non-empty bin
-__global__ __launch_bounds__(SORT_THREADS) void order_hist_kernel(const uint64_t* __restrict__ keys, uint32_t n, int shift, uint32_t* __restrict__ hist) {
+// Per workgroup a histogram in LDS; its flush reserves the workgroup's share of every bin: block_base[b][bin] = how many
+// reads of that bin the workgroups that flushed earlier hold (whichever they are: the order inside a bin is free).
+__global__ __launch_bounds__(SORT_THREADS) void order_hist_kernel(const uint64_t* __restrict__ keys, uint32_t n, int shift, uint32_t* __restrict__ hist,
+                                                                 uint32_t* __restrict__ block_base) {
     __shared__ uint32_t h[ORDER_BINS];
     for (uint32_t i = threadIdx.x; i < ORDER_BINS; i += SORT_THREADS) h[i] = 0;
     __syncthreads();
@@ -31,7 +33,8 @@ __global__ __launch_bounds__(SORT_THREADS) void order_hist_kernel(const uint64_t
         if (r < n) atomicAdd(&h[bin_of(keys[r], shift)], 1u);
     }
     __syncthreads();
-    for (uint32_t i = threadIdx.x; i < ORDER_BINS; i += SORT_THREADS) if (h[i]) atomicAdd(&hist[i], h[i]);
+    for (uint32_t i = threadIdx.x; i < ORDER_BINS; i += SORT_THREADS)
+        block_base[(size_t)blockIdx.x * ORDER_BINS + i] = h[i] ? atomicAdd(&hist[i], h[i]) : 0u;
 }
 
 // exclusive scan of the ORDER_BINS counts, in place: hist[i] becomes where bin i starts (one workgroup)
@@ -54,30 +57,36 @@ __global__ __launch_bounds__(1024) void order_scan_kernel(uint32_t* __restrict__
     for (uint32_t q = 0; q < PER; ++q) { hist[threadIdx.x * PER + q] = at; at += v[q]; }
 }
 
-// read r goes to the next free place of its bin (the cursors start where the scan left them)
-__global__ __launch_bounds__(SORT_THREADS) void order_scatter_kernel(const uint64_t* __restrict__ keys, uint32_t n, int shift, uint32_t* __restrict__ cursor,
-                                                                    uint32_t* __restrict__ idx_out) {
+// read r goes to: start of its bin + its workgroup's share + its rank inside the workgroup (an LDS atomic)
+__global__ __launch_bounds__(SORT_THREADS) void order_scatter_kernel(const uint64_t* __restrict__ keys, uint32_t n, int shift, const uint32_t* __restrict__ start,
+                                                                    const uint32_t* __restrict__ block_base, uint32_t* __restrict__ idx_out) {
+    __shared__ uint32_t at[ORDER_BINS];
+    for (uint32_t i = threadIdx.x; i < ORDER_BINS; i += SORT_THREADS) at[i] = start[i] + block_base[(size_t)blockIdx.x * ORDER_BINS + i];
+    __syncthreads();
     const uint32_t base = blockIdx.x * (SORT_THREADS * SORT_PER_THREAD);
 #pragma unroll
     for (int q = 0; q < SORT_PER_THREAD; ++q) {
         const uint32_t r = base + q * SORT_THREADS + threadIdx.x;
-        if (r < n) idx_out[atomicAdd(&cursor[bin_of(keys[r], shift)], 1u)] = r;
+        if (r < n) idx_out[atomicAdd(&at[bin_of(keys[r], shift)], 1u)] = r;
     }
 }
 
 }  // namespace
 
-size_t order_temp_bytes() { return ORDER_BINS * sizeof(uint32_t); }
+static uint32_t order_blocks(uint32_t n) { return (n + SORT_THREADS * SORT_PER_THREAD - 1) / (SORT_THREADS * SORT_PER_THREAD); }
+
+size_t order_temp_bytes(uint32_t n) { return (1 + (size_t)order_blocks(n)) * ORDER_BINS * sizeof(uint32_t); }
 
 hipError_t order_reads(void* tmp, const uint64_t* keys, uint32_t* idx_out, uint32_t n, int key_bits, hipStream_t stream) {
     uint32_t* hist = static_cast<uint32_t*>(tmp);
+    uint32_t* block_base = hist + ORDER_BINS;
     const int shift = key_bits > ORDER_BIN_BITS ? key_bits - ORDER_BIN_BITS : 0;
     hipError_t e = hipMemsetAsync(hist, 0, ORDER_BINS * sizeof(uint32_t), stream);
     if (e != hipSuccess) return e;
-    const uint32_t blocks = (n + SORT_THREADS * SORT_PER_THREAD - 1) / (SORT_THREADS * SORT_PER_THREAD);
-    hipLaunchKernelGGL(order_hist_kernel, dim3(blocks), dim3(SORT_THREADS), 0, stream, keys, n, shift, hist);
+    const uint32_t blocks = order_blocks(n);
+    hipLaunchKernelGGL(order_hist_kernel, dim3(blocks), dim3(SORT_THREADS), 0, stream, keys, n, shift, hist, block_base);
     hipLaunchKernelGGL(order_scan_kernel, dim3(1), dim3(1024), 0, stream, hist);
-    hipLaunchKernelGGL(order_scatter_kernel, dim3(blocks), dim3(SORT_THREADS), 0, stream, keys, n, shift, hist, idx_out);
+    hipLaunchKernelGGL(order_scatter_kernel, dim3(blocks), dim3(SORT_THREADS), 0, stream, keys, n, shift, (const uint32_t*)hist, (const uint32_t*)block_base, idx_out);
     return hipGetLastError();
 }
 
