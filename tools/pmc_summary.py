@@ -1,7 +1,7 @@
 """Fold rocprofv3 --pmc CSVs (separate passes) into per-kernel, per-launch means.
 usage: pmc_summary.py <dir> [--command "<the profiled command, as run>"]
 The counter names come from the CSVs themselves; the dominant kernel is the placement kernel with the most FETCH_SIZE
-over all its launches when that counter was collected, else the one with the most launches (the bench's timed steps:
+over all its launches when that counter was collected, else the one with the largest total of a cycle / instruction counter (the bench's timed steps:
 the single statistics launch of the untimed preamble is a different template instance)."""
 import collections
 import csv
@@ -34,7 +34,12 @@ have_fetch = any("FETCH_SIZE" in out[k] for k in place)
 if have_fetch:
     dom = max(place, key=lambda k: out[k].get("FETCH_SIZE", {}).get("per_launch_mean", 0) * out[k].get("FETCH_SIZE", {}).get("launches", 0), default=None)
 else:  # no byte counter in these passes: the instance the timed steps launched most often
-    dom = max(place, key=lambda k: (max((c["launches"] for c in out[k].values()), default=0), -len(k)), default=None)
+    def weight(k):  # total of the first counter that says how much the kernel ran
+        for c in ("SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_INSTS_VALU", "TCC_REQ_sum", "TCP_TCC_READ_REQ_sum"):
+            if c in out[k]:
+                return out[k][c]["per_launch_mean"] * out[k][c]["launches"]
+        return max((c["launches"] for c in out[k].values()), default=0)
+    dom = max(place, key=weight, default=None)
 counters = sorted({c for k in out for c in out[k]})
 res = {
     "command": command or "(not recorded)",
