@@ -8,6 +8,15 @@
 
 namespace cls {
 
+// LDS-tiled long-read kernel (cls_tile.hip): binary FMT_SPLIT index with a direct table.
+struct TilePlan {
+    uint32_t threads, lookups, bases, cap_kmers, grid, set_words;  // the configuration that gives a read a whole CU's LDS
+    size_t smem;
+    uint32_t half_grid, half_set_words, half_cap_entries;          // two workgroups per CU (half_grid == 0: not for reads this long)
+    size_t half_smem;
+    uint64_t scratch_words;                                        // global scratch of the resident workgroups
+};
+
 // Grid sizes + scratch layout of one placement batch.
 struct PlacePlan {
     uint32_t grid[2];          // workgroups per wave-per-read class
@@ -30,17 +39,18 @@ struct PlacePlan {
     uint32_t tile_bases;       // bases per read its LDS holds
     uint32_t tile_cap_kmers;   // the same as a k-mer count (classification bound)
     size_t tile_smem;          // dynamic LDS of that kernel
+    TilePlan tile;             // the whole plan of that class (cls_tile.hip)
+    uint64_t tile_off_words;   // its scratch + the list of reads handed from the two-per-CU launch to the one-per-CU one
     uint64_t ws_bytes;         // device scratch the launch needs
 };
-// LDS-tiled long-read kernel (cls_tile.hip): binary FMT_SPLIT index with a direct table.
-struct TilePlan { uint32_t threads, lookups, bases, cap_kmers, grid; size_t smem; };
+// LDS-tiled long-read kernel (cls_tile.hip): launch interface
 bool tile_usable(const DbDev& db);
 TilePlan tile_plan(const DbDev& db, uint32_t want_kmers, uint32_t n_long, uint32_t n_cu);
 std::string tile_kernel_name(const DbDev& db, bool stats, uint32_t threads);
 // reads of `list` (device, *list_len of them) -> records; reads its code set cannot hold are appended to `spill_list`
 void tile_launch(const DbDev& db, const PlaceParams& prm, const TilePlan& p, bool stats, const uint8_t* d_bases, const uint64_t* d_offsets,
                  const uint32_t* list, const uint32_t* list_len, cls_placement* d_out, cls_query_stats* d_stats, uint32_t* spill_list,
-                 uint32_t* spill_len, hipStream_t stream);
+                 uint32_t* spill_len, uint32_t* scratch, uint32_t* big_list, uint32_t* big_len, hipStream_t stream);
 // `long_cap`: k-mer capacity wanted for reads beyond MAX_READ_KMERS (0 = refuse them), `n_long`: how many
 // such reads the batch may hold (bounds the number of workspace slices).
 PlacePlan plan_place(const DbDev& db, uint32_t n_reads, uint32_t n_cu, bool stats, uint32_t long_cap, uint32_t n_long);

@@ -2524,8 +2524,12 @@ PlacePlan plan_place(const DbDev& db, uint32_t n_reads, uint32_t n_cu, bool stat
     // LDS-tiled long-read class (binary FMT_SPLIT index with a direct table): as many lookups per read as 160 KB of LDS hold
     if (long_cap > MAX_READ_KMERS && n_long && tile_usable(db)) {  // (cls_tile.hip)
         const TilePlan tp = tile_plan(db, long_cap, n_long, n_cu);
-        p.grid_tile = tp.grid; p.tile_threads = tp.threads; p.tile_lookups = tp.lookups;
+        p.tile = tp;
+        p.grid_tile = tp.half_grid ? tp.half_grid : tp.grid; p.tile_threads = tp.half_grid ? 512u : tp.threads; p.tile_lookups = tp.lookups;
         p.tile_bases = tp.bases; p.tile_smem = tp.smem; p.tile_cap_kmers = tp.cap_kmers;
+        p.tile_off_words = w;
+        w += tp.scratch_words + n_reads;
+        w += w & 1;
     }
     // long-read class: per workgroup two state buffers (the distinct-hit set shares the second) + child counters
     if (long_cap > MAX_READ_KMERS && n_long) {
@@ -2684,8 +2688,9 @@ hipError_t launch_place(const DbDev& db, const PlaceParams& prm, const PlacePlan
     if (plan.grid_tile) {  // class 3: long reads, every state in LDS; reads it cannot hold are appended to class 4's list
         if (hipGetLastError() != hipSuccess) return hipErrorLaunchFailure;
         if (ev_start) (void)hipEventRecord(ev_start, stream);
-        const TilePlan tp{plan.tile_threads, plan.tile_lookups, plan.tile_bases, plan.tile_cap_kmers, plan.grid_tile, plan.tile_smem};
-        tile_launch(db, prm, tp, st, d_bases, d_offsets, lists[3], counts + 3, d_out, d_stats, lists[4], counts + 4, stream);
+        uint32_t* tile_ws = d_ws + plan.tile_off_words;
+        tile_launch(db, prm, plan.tile, st, d_bases, d_offsets, lists[3], counts + 3, d_out, d_stats, lists[4], counts + 4,
+                    tile_ws, tile_ws + plan.tile.scratch_words, counts + 5, stream);
         if (ev_stop) (void)hipEventRecord(ev_stop, stream);
     }
     if (plan.grid_long) {  // class 4: reads beyond what the LDS holds (and every long read of the other index shapes): state in the workspace

@@ -54,9 +54,16 @@ struct RtSh {
 };
 
 __host__ __device__ inline uint32_t rt_packed_words(uint32_t max_bases) { return ((max_bases + 15) / 16 + 2 + 3) & ~3u; }
-// dynamic LDS for reads of up to `max_lookups` table lookups and `max_bases` bases
-__host__ __device__ inline size_t rt_smem(uint32_t max_lookups, uint32_t max_bases) {
-    return 4ull * rt_packed_words(max_bases) + 8ull * max_lookups + 4ull * max_lookups + 16;
+// Dynamic LDS: the FRONT holds the packed read, one word per lookup and the set of codes; the DESCENT, over the same
+// bytes, 12 bytes per entry.  The entries travel from the one to the other through the workgroup's slot of a global
+// scratch (L2-resident: 12 bytes x max_lookups per resident workgroup), so that neither phase pays for the other's LDS.
+__host__ __device__ inline uint32_t rt_scratch_words(uint32_t max_lookups) { return (3u * max_lookups + 1u) & ~1u; }  // a workgroup's slot: 12 bytes per lookup, 8-byte aligned
+__host__ __device__ inline size_t rt_front_bytes(uint32_t max_lookups, uint32_t max_bases, uint32_t set_words) {
+    return 4ull * rt_packed_words(max_bases) + 4ull * max_lookups + 4ull * set_words;
+}
+__host__ __device__ inline size_t rt_smem(uint32_t max_lookups, uint32_t max_bases, uint32_t set_words, uint32_t cap_entries) {
+    const size_t f = rt_front_bytes(max_lookups, max_bases, set_words), d = 12ull * cap_entries;
+    return (f > d ? f : d) + 16;
 }
 
 // position of this thread's element in a list that all threads of the workgroup append to (wave-aggregated)
@@ -75,15 +82,19 @@ __global__ __launch_bounds__(THREADS) void place_tile_kernel(DbDev db, PlacePara
                                                              const uint64_t* __restrict__ offsets, const uint32_t* __restrict__ list,
                                                              const uint32_t* __restrict__ list_len, cls_placement* __restrict__ out,
                                                              cls_query_stats* __restrict__ stats, uint32_t max_lookups, uint32_t max_bases,
-                                                             uint32_t pass_codes, uint32_t set_words, uint32_t* __restrict__ spill_list, uint32_t* __restrict__ spill_len) {
+                                                             uint32_t pass_codes, uint32_t set_words, uint32_t* __restrict__ spill_list, uint32_t* __restrict__ spill_len,
+                                                             uint32_t cap_entries, uint32_t* __restrict__ gws, uint32_t* __restrict__ big_list, uint32_t* __restrict__ big_len) {
     extern __shared__ __align__(16) uint8_t smem[];
     __shared__ RtSh sh;
+    // front: [packed read][one word per lookup][set of codes]; descent, over the same bytes: [entries 8 B][their split records 4 B]
     uint32_t* const packed = reinterpret_cast<uint32_t*>(smem);
-    uint2* const ent = reinterpret_cast<uint2*>(packed + rt_packed_words(max_bases));
-    uint32_t* const cset = reinterpret_cast<uint32_t*>(ent);  // front only: the set of codes that makes the k-mers distinct lies over the
-                                                              // entries (made after it is done): 2 * max_lookups words, one pass at load <= 0.5            // {LO = first tip << 8 | weight, HI = last tip << 8}; dead: {RT_DEAD_LO, 0}
-    uint32_t* const xs = reinterpret_cast<uint32_t*>(ent + max_lookups);           // split record of the entry's set
-    uint32_t* const wsid = xs;  // front only: per window its tip-set id | bit 31 (the lookup stands for ONE k-mer) if it is the first with its code, else 0
+    uint32_t* const wsid = packed + rt_packed_words(max_bases);  // per window its tip-set id | bit 31 (the lookup stands for ONE k-mer) if it is the first with its code, else 0
+    uint32_t* const cset = wsid + max_lookups;                    // the set of codes that makes the k-mers distinct
+    uint2* const ent = reinterpret_cast<uint2*>(smem);            // {LO = first tip << 8 | weight, HI = last tip << 8}; dead: {RT_DEAD_LO, 0}
+    uint32_t* const xs = reinterpret_cast<uint32_t*>(ent + cap_entries);  // split record of the entry's set
+    // this workgroup's slot of the global scratch: the entries as the front makes them
+    uint2* const g_ent = reinterpret_cast<uint2*>(gws + (size_t)blockIdx.x * rt_scratch_words(max_lookups));
+    uint32_t* const g_xs = reinterpret_cast<uint32_t*>(g_ent + max_lookups);
     const uint32_t tid = threadIdx.x, lane = tid & 63;
     const uint32_t k = db.k;
     const uint32_t kmask = (1u << (2 * k)) - 1u;  // k <= 15
@@ -201,15 +212,13 @@ __global__ __launch_bounds__(THREADS) void place_tile_kernel(DbDev db, PlacePara
         // ---- A2b. entries.  Consecutive windows mostly share their tip set (a set's k-mers are the windows between two
         // mutation boundaries of a lineage): runs of equal set ids among a wavefront's 64 consecutive windows become
         // ONE entry weighted by the run, and only the run's head reads the 16-byte set record (RT_LOOK records in
-        // flight per thread).  The entries are appended to `ent` / `xs`; xs lies over wsid: a block of RT_LOOK *
-        // THREADS windows is read by everyone before any entry of it is written (entry index <= window index). ----
+        // flight per thread).  The entries are appended to the workgroup's slot of the global scratch. ----
         uint32_t nm_t = 0, nroot_t = 0;
         uint64_t leafp_t = 0;
         for (uint32_t jb = 0; jb < n_look; jb += RT_LOOK * THREADS) {
             uint32_t v[RT_LOOK];
 #pragma unroll
             for (int q = 0; q < RT_LOOK; ++q) { const uint32_t j = jb + q * THREADS + tid; v[q] = j < n_look ? wsid[j] : 0u; }
-            __syncthreads();
             uint4 sr[RT_LOOK];
             uint32_t wq[RT_LOOK];
 #pragma unroll
@@ -240,8 +249,8 @@ __global__ __launch_bounds__(THREADS) void place_tile_kernel(DbDev db, PlacePara
                 const bool live = w != 0 && has_root && has_tips;
                 const uint32_t g = rt_append(live, &sh.n_groups, lane);
                 if (live) {
-                    ent[g] = uint2{((sr[q].y & RT_TIP_MASK) << 8) | w, (sr[q].z & RT_TIP_MASK) << 8};
-                    xs[g] = sr[q].x;
+                    g_ent[g] = uint2{((sr[q].y & RT_TIP_MASK) << 8) | w, (sr[q].z & RT_TIP_MASK) << 8};
+                    g_xs[g] = sr[q].x;
                 }
             }
         }
@@ -274,6 +283,21 @@ __global__ __launch_bounds__(THREADS) void place_tile_kernel(DbDev db, PlacePara
             const uint64_t exp_usize = (expected != expected) ? 0ull : (uint64_t)expected;
             if ((uint64_t)n_root < exp_usize) { finish_stats(); record(CLS_UNCLASSIFIABLE_COVERAGE, (int32_t)n_root, 0, 0, 0); continue; }
         }
+        // ---- the entries come back from the scratch into the LDS the front has left (a read with more of them than this
+        // configuration holds goes to the launch that gives a read the whole LDS) ----
+        if (n_groups > cap_entries) {
+            if (tid == 0) big_list[atomicAdd(big_len, 1u)] = r;
+            continue;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __syncthreads();  // (every entry is written, every use of the front's LDS is over)
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        for (uint32_t j = tid; j < n_groups; j += THREADS) {  // (L2-served loads: the lines may sit in this CU's L1 from the read before)
+            const unsigned long long e = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(g_ent + j), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            ent[j] = uint2{(uint32_t)e, (uint32_t)(e >> 32)};
+            xs[j] = __hip_atomic_load(g_xs + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
         // ---- C. descent (place_sequence.rs:279-601) -----------------------------------------------------------------------
         // Every thread owns the same entries at every level (j = tid, tid + THREADS, ...): what it lists it settles and
         // counts itself, no barrier between those.  Both children's node records arrive a level ahead (one 64-byte
@@ -402,6 +426,10 @@ bool tile_usable(const DbDev& db) {
     return db.format == FMT_SPLIT && db.binary_tree && db.direct != nullptr && db.n_nodes < RT_TIP_MASK && !tuning().no_tile;
 }
 
+// Two configurations of the one kernel.  WHOLE: a read has the whole LDS of a CU (one 1024-thread workgroup per CU; as many
+// lookups as 160 KB hold, the code set in one pass).  HALF, when the longest read's front fits half a CU (two 512-thread
+// workgroups per CU, their dependent chains overlapping: 1.45x per read measured on 5 kb reads): the code set is smaller
+// (passes over hash partitions) and a read with more entries than 12 bytes x 80 KB hold is handed to a WHOLE launch.
 TilePlan tile_plan(const DbDev& db, uint32_t want_kmers, uint32_t n_long, uint32_t n_cu) {
     TilePlan p{};
     const bool canon = db.canonical != 0;
@@ -409,18 +437,28 @@ TilePlan tile_plan(const DbDev& db, uint32_t want_kmers, uint32_t n_long, uint32
     auto bases_of = [&](uint32_t look) { return (canon ? look : look / 2) + db.k; };
     uint32_t look = want;
     const size_t lds_max = 160 * 1024 - sizeof(RtSh) - 256;
-    if (rt_smem(look, bases_of(look)) > lds_max) {  // as many lookups per read as 160 KB of LDS hold; longer reads: the workspace kernel
+    if (rt_smem(look, bases_of(look), 2 * look, look) > lds_max) {  // as many lookups per read as 160 KB of LDS hold; longer reads: the workspace kernel
         look = (uint32_t)((lds_max - 64 - 4ull * 8) / 12);
-        while (look > 64 && rt_smem(look, bases_of(look)) > lds_max) look -= 64;
+        while (look > 64 && rt_smem(look, bases_of(look), 2 * look, look) > lds_max) look -= 64;
     }
     look = std::min<uint32_t>(look, 32767u);  // weights are summed in 16-bit halves
     p.lookups = look;
     p.bases = bases_of(look);
-    p.smem = rt_smem(p.lookups, p.bases);
-    const uint32_t per_cu = (uint32_t)std::min<size_t>(2, (160 * 1024) / (p.smem + sizeof(RtSh) + 256));
-    p.threads = per_cu >= 2 ? 512u : 1024u;
-    p.grid = std::max<uint32_t>(1, std::min<uint32_t>(n_long, n_cu * (p.threads == 512u ? 2u : 1u)));
+    p.smem = rt_smem(look, p.bases, 2 * look, look);
+    p.set_words = 2 * look;
+    p.threads = 1024u;
+    p.grid = std::max<uint32_t>(1, std::min<uint32_t>(n_long, n_cu));
     p.cap_kmers = canon ? 2 * look : look;
+    // the HALF configuration: what is left of 80 KB after the packed read and the word per lookup is the code set
+    const size_t half_max = 79 * 1024 - sizeof(RtSh) - 256;  // (two of them, their static LDS and the allocation granule inside 160 KB)
+    const size_t fixed = rt_front_bytes(look, p.bases, 0);
+    if (!tuning().tile_one_per_cu && fixed + 4 * 4096 <= half_max) {
+        p.half_set_words = (uint32_t)((half_max - fixed) / 4);
+        p.half_cap_entries = (uint32_t)(half_max / 12);
+        p.half_smem = rt_smem(look, p.bases, p.half_set_words, p.half_cap_entries);
+        p.half_grid = std::max<uint32_t>(1, std::min<uint32_t>(n_long, 2 * n_cu));
+    }
+    p.scratch_words = (uint64_t)rt_scratch_words(look) * ((uint64_t)p.half_grid + p.grid);  // per resident workgroup 12 bytes per lookup (L2-resident)
     return p;
 }
 
@@ -431,17 +469,24 @@ std::string tile_kernel_name(const DbDev& db, bool stats, uint32_t threads) {
 
 void tile_launch(const DbDev& db, const PlaceParams& prm, const TilePlan& p, bool stats, const uint8_t* d_bases, const uint64_t* d_offsets,
                  const uint32_t* list, const uint32_t* list_len, cls_placement* d_out, cls_query_stats* d_stats, uint32_t* spill_list,
-                 uint32_t* spill_len, hipStream_t stream) {
-    const void* kfn = tile_kernel(p.threads, db.canonical != 0, stats, db.addr32 != 0);
-    (void)hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.smem);
-    // the code set: two words per lookup the LDS is provisioned for, every code in one pass (knobs: fewer words / codes per pass)
+                 uint32_t* spill_len, uint32_t* scratch, uint32_t* big_list, uint32_t* big_len, hipStream_t stream) {
     uint32_t max_lookups = p.lookups, max_bases = p.bases;
-    uint32_t set_words = 2 * p.lookups, pass_codes = p.lookups;
-    if (tuning().tile_set_words > 0) set_words = std::min<uint32_t>(set_words, (uint32_t)tuning().tile_set_words);
-    if (tuning().tile_pass_codes > 0) pass_codes = (uint32_t)tuning().tile_pass_codes;
-    void* args[] = {(void*)&db, (void*)&prm, (void*)&d_bases, (void*)&d_offsets, (void*)&list, (void*)&list_len, (void*)&d_out, (void*)&d_stats,
-                    (void*)&max_lookups, (void*)&max_bases, (void*)&pass_codes, (void*)&set_words, (void*)&spill_list, (void*)&spill_len};
-    (void)hipLaunchKernel(kfn, dim3(p.grid), dim3(p.threads), args, p.smem, stream);
+    auto launch = [&](uint32_t threads, uint32_t grid, size_t smem, uint32_t set_words, uint32_t cap_entries, const uint32_t* lst, const uint32_t* len, uint32_t* gws) {
+        const void* kfn = tile_kernel(threads, db.canonical != 0, stats, db.addr32 != 0);
+        (void)hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        // the code set: every code in one pass at load <= 0.5 (knobs: fewer words / codes per pass -- tests)
+        if (tuning().tile_set_words > 0) set_words = std::min<uint32_t>(set_words, (uint32_t)tuning().tile_set_words);
+        uint32_t pass_codes = std::max<uint32_t>(1u, set_words / 2);
+        if (tuning().tile_pass_codes > 0) pass_codes = (uint32_t)tuning().tile_pass_codes;
+        void* args[] = {(void*)&db, (void*)&prm, (void*)&d_bases, (void*)&d_offsets, (void*)&lst, (void*)&len, (void*)&d_out, (void*)&d_stats,
+                        (void*)&max_lookups, (void*)&max_bases, (void*)&pass_codes, (void*)&set_words, (void*)&spill_list, (void*)&spill_len,
+                        (void*)&cap_entries, (void*)&gws, (void*)&big_list, (void*)&big_len};
+        (void)hipLaunchKernel(kfn, dim3(grid), dim3(threads), args, smem, stream);
+    };
+    if (p.half_grid) {
+        launch(512u, p.half_grid, p.half_smem, p.half_set_words, p.half_cap_entries, list, list_len, scratch);
+        launch(1024u, p.grid, p.smem, p.set_words, p.lookups, big_list, big_len, scratch + (uint64_t)rt_scratch_words(p.lookups) * p.half_grid);  // the reads with more entries
+    } else launch(1024u, p.grid, p.smem, p.set_words, p.lookups, list, list_len, scratch);
 }
 
 }  // namespace cls

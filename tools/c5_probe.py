@@ -1,6 +1,6 @@
 """Experiment: BASELINE config 5 at a given scale through the device-buffer entry; time per launch as a function of the
 iteration cap (1 = the front alone, then the cost per level), and the per-read counters.
-usage: c5_probe.py <scale> [n_reads]      (CLS_NO_TILE=1: the workspace kernel instead of the LDS-tiled one)"""
+usage: c5_probe.py <scale> [n_reads] [read_len]      (CLS_NO_TILE=1: the workspace kernel instead of the LDS-tiled one)"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -10,6 +10,8 @@ from classeq2_amd.synth import CONFIGS, SynthDb
 scale = float(sys.argv[1]) if len(sys.argv) > 1 else 0.1
 cfg = CONFIGS["C5"]
 n = int(sys.argv[2]) if len(sys.argv) > 2 else max(2000, int(cfg["n_reads"] * scale * 0.2))
+if len(sys.argv) > 3:
+    cfg = dict(cfg, read_len=int(sys.argv[3]))
 t0 = time.time()
 s = SynthDb(max(64, int(cfg["n_leaves"] * scale)), cfg["ref_len"], cfg["k_size"], cfg["m_size"], deep=1, max_depth=900, tips_only=True)
 db = engine.PlacementDb(s.flat, device=0)
