@@ -2,16 +2,20 @@
 // BASELINE config 5 (10 kb reads, k = 15, deep tree); binary FMT_SPLIT indexes with a direct table.
 //
 // The algorithm is place_sequence.rs:42-601 as in cls_kernels.hip (A: k-mers + lookup + distinct hashes,
-// B: thresholds, C: descent).  Layout: the read packed 2 bits per base, a set of codes that makes the k-mers distinct
-// (over the entries' space, which it precedes in time), and one ENTRY per run of consecutive
-// windows that share a tip set: {first tip << 8 | weight, last tip << 8} + the set's split record, 12 bytes of LDS.
+// B: thresholds, C: descent).  LDS, first the FRONT's: the read packed 2 bits per base, one word per lookup, the set of codes
+// that makes the k-mers distinct; then, over the same bytes, the DESCENT's: one ENTRY per run of consecutive windows that
+// share a tip set, {first tip << 8 | weight, last tip << 8} + the set's split record = 12 bytes.  The entries pass from the
+// one to the other through the workgroup's slot of a small global scratch (L2-resident), so neither phase pays for the other's
+// LDS: a 10 kb read's front fits half a CU, and so do the entries of most reads -- two workgroups per CU; a read with more
+// entries than that is handed to a second launch that gives a read the whole LDS (tile_plan below).
 // What the descent is built around (on a 150-level ladder tree a level costs what its dependent chain costs):
 //   * a level is DECIDED by the sign of |K_a| - |K_b| (both `remove_intersection` values): one pass
 //     over the entries, two compares each, ONE packed sum per thread, one wave reduction, one barrier; the three counts
 //     of the record are taken once, at the level the descent ends at;
 //   * narrowing touches only an entry with a tip OUTSIDE the chosen child: it dies, or -- tips on both sides -- reads
 //     ONE 8-byte half of its split record (kmers_map.rs:189-203 answered from the split tree); every other entry costs
-//     one LDS read and three compares a level.
+//     one LDS read and a handful of compares a level.  At 10 kb the level loop is bound by instruction issue (about 28
+//     instructions per entry and level), not by latency: a second workgroup per CU buys 6 %, on 5 kb reads 45 %.
 // (Measured and rejected, round 3: the entries in registers, 20 per thread of a 512-thread workgroup, two workgroups per
 // CU -- the unrolled per-slot code costs more instructions than the second workgroup hides; halves read asynchronously
 // and applied a level later, the level decided early when |K_a| - |K_b| exceeds the weight still in flight -- it hides
