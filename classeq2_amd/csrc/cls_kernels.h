@@ -10,7 +10,7 @@ namespace cls {
 
 // LDS-tiled long-read kernel (cls_tile.hip): binary FMT_SPLIT index with a direct table.
 struct TilePlan {
-    uint32_t threads, lookups, bases, cap_kmers, grid, set_words;  // the configuration that gives a read a whole CU's LDS
+    uint32_t threads, lookups, bases, cap_kmers, grid, set_words, cap_entries;  // the configuration that gives a read a whole CU's LDS
     size_t smem;
     uint32_t half_grid, half_set_words, half_cap_entries;          // two workgroups per CU (half_grid == 0: not for reads this long)
     size_t half_smem;

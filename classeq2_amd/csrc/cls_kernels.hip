@@ -165,22 +165,6 @@ __device__ __forceinline__ void hash_kmer_and_prefix(const uint8_t* p, uint32_t 
     mz_out = mz;
 }
 
-// MurmurHash3_x64_128(p[0..len), seed 0).0 with the message fetched eight bytes at a time (gfx950 reads unaligned
-// 64-bit words from LDS in one ds_read_b64).  Reads up to 15 bytes past the message, inside the caller's LDS buffer.
-__device__ __forceinline__ uint64_t lds_u64(const uint8_t* p) { uint64_t v; __builtin_memcpy(&v, p, 8); return v; }
-__device__ __forceinline__ uint64_t murmur3_h1_lds(const uint8_t* p, uint32_t len) {
-    Mur3 m;
-    const uint32_t nblocks = len >> 4;
-#pragma unroll 1
-    for (uint32_t b = 0; b < nblocks; ++b) m.block(lds_u64(p + 16 * b), lds_u64(p + 16 * b + 8));
-    const uint32_t t = len & 15u;
-    const uint8_t* tail = p + 16 * nblocks;
-    uint64_t k1 = 0, k2 = 0;
-    if (t > 0) { k1 = lds_u64(tail); if (t < 8) k1 &= (1ull << (8 * t)) - 1; }
-    if (t > 8) { k2 = lds_u64(tail + 8) & ((1ull << (8 * (t - 8))) - 1); }
-    return m.finish(k1, k2, t, len);
-}
-
 struct WaveCtx {
     uint8_t* seq;    // LDS: upper-cased read
     uint32_t* set;   // LDS: distinct-hit set (keys = table slot indices)

@@ -58,15 +58,17 @@ struct RtSh {
 };
 
 __host__ __device__ inline uint32_t rt_packed_words(uint32_t max_bases) { return ((max_bases + 15) / 16 + 2 + 3) & ~3u; }
+__host__ __device__ inline uint32_t rt_seq_words(uint32_t max_bases) { return ((2 * max_bases + 16 + 15) / 16) * 4; }  // ASCII, both strands, 16 bytes of slack for the 8-byte hash reads
 // Dynamic LDS: the FRONT holds the packed read, one word per lookup and the set of codes; the DESCENT, over the same
 // bytes, 12 bytes per entry.  The entries travel from the one to the other through the workgroup's slot of a global
 // scratch (L2-resident: 12 bytes x max_lookups per resident workgroup), so that neither phase pays for the other's LDS.
 __host__ __device__ inline uint32_t rt_scratch_words(uint32_t max_lookups) { return (3u * max_lookups + 1u) & ~1u; }  // a workgroup's slot: 12 bytes per lookup, 8-byte aligned
-__host__ __device__ inline size_t rt_front_bytes(uint32_t max_lookups, uint32_t max_bases, uint32_t set_words) {
-    return 4ull * rt_packed_words(max_bases) + 4ull * max_lookups + 4ull * set_words;
+__host__ __device__ inline size_t rt_front_bytes(uint32_t max_lookups, uint32_t max_bases, uint32_t set_words, bool hashed) {
+    return hashed ? 4ull * rt_seq_words(max_bases) + 4ull * set_words
+                  : 4ull * rt_packed_words(max_bases) + 4ull * max_lookups + 4ull * set_words;
 }
-__host__ __device__ inline size_t rt_smem(uint32_t max_lookups, uint32_t max_bases, uint32_t set_words, uint32_t cap_entries) {
-    const size_t f = rt_front_bytes(max_lookups, max_bases, set_words), d = 12ull * cap_entries;
+__host__ __device__ inline size_t rt_smem(uint32_t max_lookups, uint32_t max_bases, uint32_t set_words, uint32_t cap_entries, bool hashed) {
+    const size_t f = rt_front_bytes(max_lookups, max_bases, set_words, hashed), d = 12ull * cap_entries;
     return (f > d ? f : d) + 16;
 }
 
@@ -81,19 +83,23 @@ __device__ __forceinline__ uint32_t rt_append(bool keep, uint32_t* counter, uint
     return base + (uint32_t)__popcll(m & ((1ull << lane) - 1));
 }
 
-template <int THREADS, bool CANON, bool STATS, bool ADDR32>
+// FRONT: 0 = direct table, one lookup per k-mer; 1 = direct table of a strand-symmetric index, one lookup per window;
+// 2 = no direct table (k > 15): MurmurHash3 + hash-table probe per k-mer of both strands (kmers_map.rs:157-159, :273-311)
+template <int THREADS, int FRONT, bool STATS, bool ADDR32>
 __global__ __launch_bounds__(THREADS) void place_tile_kernel(DbDev db, PlaceParams prm, const uint8_t* __restrict__ bases,
                                                              const uint64_t* __restrict__ offsets, const uint32_t* __restrict__ list,
                                                              const uint32_t* __restrict__ list_len, cls_placement* __restrict__ out,
                                                              cls_query_stats* __restrict__ stats, uint32_t max_lookups, uint32_t max_bases,
                                                              uint32_t pass_codes, uint32_t set_words, uint32_t* __restrict__ spill_list, uint32_t* __restrict__ spill_len,
                                                              uint32_t cap_entries, uint32_t* __restrict__ gws, uint32_t* __restrict__ big_list, uint32_t* __restrict__ big_len) {
+    constexpr bool CANON = FRONT == 1, HASHED = FRONT == 2;
     extern __shared__ __align__(16) uint8_t smem[];
     __shared__ RtSh sh;
     // front: [packed read][one word per lookup][set of codes]; descent, over the same bytes: [entries 8 B][their split records 4 B]
     uint32_t* const packed = reinterpret_cast<uint32_t*>(smem);
-    uint32_t* const wsid = packed + rt_packed_words(max_bases);  // per window its tip-set id | bit 31 (the lookup stands for ONE k-mer) if it is the first with its code, else 0
-    uint32_t* const cset = wsid + max_lookups;                    // the set of codes that makes the k-mers distinct
+    uint8_t* const seq = smem;                                    // HASHED: the read upper-cased, then its reverse complement (2 * max_bases + 16 bytes)
+    uint32_t* const wsid = packed + rt_packed_words(max_bases);   // per window its tip-set id | bit 31 (the lookup stands for ONE k-mer) if it is the first with its code, else 0
+    uint32_t* const cset = HASHED ? packed + rt_seq_words(max_bases) : wsid + max_lookups;  // the set of codes (HASHED: table slots; no word per lookup) that makes the k-mers distinct
     uint2* const ent = reinterpret_cast<uint2*>(smem);            // {LO = first tip << 8 | weight, HI = last tip << 8}; dead: {RT_DEAD_LO, 0}
     uint32_t* const xs = reinterpret_cast<uint32_t*>(ent + cap_entries);  // split record of the entry's set
     // this workgroup's slot of the global scratch: the entries as the front makes them
@@ -101,7 +107,7 @@ __global__ __launch_bounds__(THREADS) void place_tile_kernel(DbDev db, PlacePara
     uint32_t* const g_xs = reinterpret_cast<uint32_t*>(g_ent + max_lookups);
     const uint32_t tid = threadIdx.x, lane = tid & 63;
     const uint32_t k = db.k;
-    const uint32_t kmask = (1u << (2 * k)) - 1u;  // k <= 15
+    const uint32_t kmask = HASHED ? 0u : (1u << (2 * (k & 15u))) - 1u;  // (direct table: k <= 15)
     const uint32_t* __restrict__ direct = db.direct;
     const uint4* __restrict__ sets = reinterpret_cast<const uint4*>(db.sets);
     const uint32_t* __restrict__ half = db.postings;
@@ -132,24 +138,38 @@ __global__ __launch_bounds__(THREADS) void place_tile_kernel(DbDev db, PlacePara
         const uint32_t L = (uint32_t)L64, nf = L - k + 1, nk = 2 * nf;
         const uint32_t n_look = CANON ? nf : nk;
         if (n_look > max_lookups) { put_stats(nk, 0, 0, 0, 0); record(CLS_ERR_READ_TOO_LONG, 0, 0, 0, 0); continue; }
-        // ---- A1. load, validate (reverse_complement panics on non-ACGT, kmers_map.rs:440), pack 2 bits per base ----
+        // ---- A1. load, validate (reverse_complement panics on non-ACGT, kmers_map.rs:440); direct table: pack 2 bits per base;
+        // hashed: the upper-cased read followed by its reverse complement, so that query k-mer j (the forward ones first, then
+        // those of the reverse complement, kmers_map.rs:387-395) is k contiguous bytes ----
         bool bad = false;
-        const uint32_t n_words = (L + 15) >> 4;
-        for (uint32_t w = tid; w < n_words + 2; w += THREADS) {
-            uint32_t acc = 0;
-            if (16 * w < L) {
-                const uint8_t* p = bases + b0 + 16 * (uint64_t)w;
-                const uint32_t nq = L - 16 * w < 16 ? L - 16 * w : 16u;
-                for (uint32_t q = 0; q < nq; ++q) {
-                    uint8_t c = p[q];
-                    if (c >= 'a' && c <= 'z') c -= 32;
-                    bad |= !(c == 'A' || c == 'C' || c == 'G' || c == 'T');
-                    acc |= (uint32_t)((c >> 1) & 3u) << (2 * q);  // A0 C1 T2 G3
-                }
+        if constexpr (HASHED) {
+            for (uint32_t i = tid; i < L; i += THREADS) {
+                uint8_t c = bases[b0 + i];
+                if (c >= 'a' && c <= 'z') c -= 32;
+                bad |= !(c == 'A' || c == 'C' || c == 'G' || c == 'T');
+                seq[i] = c;
+                seq[2 * L - 1 - i] = c ^ ((c & 2) ? 0x04 : 0x15);  // A<->T, C<->G
             }
-            packed[w] = acc;
+        } else {
+            const uint32_t n_words = (L + 15) >> 4;
+            for (uint32_t w = tid; w < n_words + 2; w += THREADS) {
+                uint32_t acc = 0;
+                if (16 * w < L) {
+                    const uint8_t* p = bases + b0 + 16 * (uint64_t)w;
+                    const uint32_t nq = L - 16 * w < 16 ? L - 16 * w : 16u;
+                    for (uint32_t q = 0; q < nq; ++q) {
+                        uint8_t c = p[q];
+                        if (c >= 'a' && c <= 'z') c -= 32;
+                        bad |= !(c == 'A' || c == 'C' || c == 'G' || c == 'T');
+                        acc |= (uint32_t)((c >> 1) & 3u) << (2 * q);  // A0 C1 T2 G3
+                    }
+                }
+                packed[w] = acc;
+            }
         }
         if (tid == 0) { sh.n_groups = 0; sh.n_m = 0; sh.n_root = 0; sh.overflow = 0; sh.ib = 0; sh.leafp = 0; }
+        (void)seq; (void)wsid;
+        if constexpr (HASHED) for (uint32_t i = tid; i < set_words; i += THREADS) cset[i] = RT_SET_EMPTY;
         if (tid < 3) { sh.cnt[tid] = 0; sh.fin[tid] = 0; }
         if (__syncthreads_or(bad ? 1 : 0)) { put_stats(0, 0, 0, 0, 0); record(CLS_ERR_INVALID_BASE, 0, 0, 0, 0); continue; }
         // code (and palindrome flag) of lookup j: forward windows first, then those of the reverse complement (kmers_map.rs:387-395)
@@ -168,6 +188,7 @@ __global__ __launch_bounds__(THREADS) void place_tile_kernel(DbDev db, PlacePara
         // ---- A2a. the table lookups, RT_LOOK per thread in flight: wsid[j] = tip-set id | bit 31 when the lookup stands
         // for ONE k-mer (a palindrome, or an index that is not strand-symmetric); 0: the k-mer is not in the index ----
         uint32_t ib = 0;  // per thread; summed at the end
+        if constexpr (!HASHED)
         for (uint32_t j0 = tid; j0 < n_look; j0 += RT_LOOK * THREADS) {
             uint32_t sid[RT_LOOK];
             bool pal[RT_LOOK];
@@ -188,7 +209,7 @@ __global__ __launch_bounds__(THREADS) void place_tile_kernel(DbDev db, PlacePara
         // defaults make it passes over hash partitions of the codes, and a partition that does not fit spills the read:
         // tests); a later window with the same code drops out
         // (a thread only ever touches its own words of wsid: no barrier between the lookups and the passes) ----
-        const uint32_t n_pass = (n_look + pass_codes - 1) / pass_codes;
+        const uint32_t n_pass = HASHED ? 0u : (n_look + pass_codes - 1) / pass_codes;  // (hashed: the lookups below go through the set as they hit)
         for (uint32_t pass = 0; pass < n_pass; ++pass) {
             if (pass) __syncthreads();  // the previous pass' set is no longer probed
             for (uint32_t i = tid; i < set_words; i += THREADS) cset[i] = RT_SET_EMPTY;
@@ -208,10 +229,12 @@ __global__ __launch_bounds__(THREADS) void place_tile_kernel(DbDev db, PlacePara
                 }
             }
         }
-        __syncthreads();
-        if (sh.overflow) {  // hand the read to the workspace kernel
-            if (tid == 0) spill_list[atomicAdd(spill_len, 1u)] = r;
-            continue;
+        if constexpr (!HASHED) {
+            __syncthreads();
+            if (sh.overflow) {  // hand the read to the workspace kernel
+                if (tid == 0) spill_list[atomicAdd(spill_len, 1u)] = r;
+                continue;
+            }
         }
         // ---- A2b. entries.  Consecutive windows mostly share their tip set (a set's k-mers are the windows between two
         // mutation boundaries of a lineage): runs of equal set ids among a wavefront's 64 consecutive windows become
@@ -221,8 +244,52 @@ __global__ __launch_bounds__(THREADS) void place_tile_kernel(DbDev db, PlacePara
         uint64_t leafp_t = 0;
         for (uint32_t jb = 0; jb < n_look; jb += RT_LOOK * THREADS) {
             uint32_t v[RT_LOOK];
+            if constexpr (HASHED) {
+                // MurmurHash3 of the k-mer, linear probing of the 16-byte slots {hash, set, bucket} (RT_LOOK probes in flight);
+                // a hit counts if its bucket's key is the k-mer's own minimizer, the hash of its first m characters
+                // (kmers_map.rs:10-13) -- the reference also accepts a bucket keyed by ANOTHER query k-mer's minimizer
+                // (kmers_map.rs:295-297): no `cls build-db` output has such an entry, and a read that meets one takes the
+                // workspace kernel, which checks it the long way.  HashSet<u64> of hashes (kmers_map.rs:273-311): one table
+                // slot per distinct hash of the index, so the first lookup to put its slot into the LDS set keeps the hit.
+                const TSlot* __restrict__ table = reinterpret_cast<const TSlot*>(db.table);
+                const uint64_t tmask = db.table_mask;
+                uint64_t h[RT_LOOK], idx[RT_LOOK];
+                TSlot sl[RT_LOOK];
 #pragma unroll
-            for (int q = 0; q < RT_LOOK; ++q) { const uint32_t j = jb + q * THREADS + tid; v[q] = j < n_look ? wsid[j] : 0u; }
+                for (int q = 0; q < RT_LOOK; ++q) {
+                    const uint32_t j = jb + q * THREADS + tid;
+                    h[q] = 0; idx[q] = 0; sl[q] = TSlot{0ull, 0u, 0u};
+                    if (j < n_look) { h[q] = murmur3_h1_lds(seq + (j < nf ? j : L + (j - nf)), k); idx[q] = h[q] & tmask; }
+                }
+#pragma unroll
+                for (int q = 0; q < RT_LOOK; ++q) if (jb + q * THREADS + tid < n_look) { sl[q] = table[idx[q]]; if (STATS) ib += 16; }
+                uint64_t bk[RT_LOOK];
+#pragma unroll
+                for (int q = 0; q < RT_LOOK; ++q) {
+                    while (sl[q].set != 0 && sl[q].hash != h[q]) { idx[q] = (idx[q] + 1) & tmask; sl[q] = table[idx[q]]; if (STATS) ib += 16; }  // (set == 0: an empty slot, the k-mer is not in the index)
+                    bk[q] = 0;
+                    if (sl[q].set != 0) { bk[q] = db.bucket_key[sl[q].bucket & (uint32_t)LOC_BUCKET_MASK]; if (STATS) ib += 8; }
+                }
+#pragma unroll
+                for (int q = 0; q < RT_LOOK; ++q) {
+                    v[q] = 0;
+                    if (sl[q].set == 0) continue;
+                    const uint32_t j = jb + q * THREADS + tid;
+                    if (murmur3_h1_lds(seq + (j < nf ? j : L + (j - nf)), db.m_eff) != bk[q]) { sh.overflow = 1; continue; }
+                    const uint32_t code = (uint32_t)idx[q];
+                    uint32_t pos = (uint32_t)(((uint64_t)(code * 2654435761u) * set_words) >> 32);
+                    for (uint32_t probes = 0;; ++probes) {
+                        if (probes == set_words) { sh.overflow = 1; break; }  // (more distinct k-mers than the set holds: spill the read)
+                        const uint32_t old = atomicCAS(&cset[pos], RT_SET_EMPTY, code);
+                        if (old == RT_SET_EMPTY) { v[q] = (sl[q].set & SET_ID_MASK) | 0x80000000u; break; }  // (every lookup stands for one k-mer)
+                        if (old == code) break;
+                        pos = pos + 1 == set_words ? 0u : pos + 1;
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < RT_LOOK; ++q) { const uint32_t j = jb + q * THREADS + tid; v[q] = j < n_look ? wsid[j] : 0u; }
+            }
             uint4 sr[RT_LOOK];
             uint32_t wq[RT_LOOK];
 #pragma unroll
@@ -267,6 +334,10 @@ __global__ __launch_bounds__(THREADS) void place_tile_kernel(DbDev db, PlacePara
             }
         }
         __syncthreads();
+        if (HASHED && sh.overflow) {  // hand the read to the workspace kernel
+            if (tid == 0) spill_list[atomicAdd(spill_len, 1u)] = r;
+            continue;
+        }
         const uint32_t n_m = sh.n_m, n_root = sh.n_root, n_groups = sh.n_groups;
         auto finish_stats = [&]() {
             if constexpr (STATS) {
@@ -413,21 +484,22 @@ __global__ __launch_bounds__(THREADS) void place_tile_kernel(DbDev db, PlacePara
     }
 }
 
-const void* tile_kernel(uint32_t threads, bool canon, bool stats, bool a32) {
-#define CLS_RT3(TH, CN, ST) (a32 ? (const void*)place_tile_kernel<TH, CN, ST, true> : (const void*)place_tile_kernel<TH, CN, ST, false>)
-#define CLS_RT2(TH, CN) (stats ? CLS_RT3(TH, CN, true) : CLS_RT3(TH, CN, false))
-#define CLS_RT1(TH) (canon ? CLS_RT2(TH, true) : CLS_RT2(TH, false))
+const void* tile_kernel(uint32_t threads, int front, bool stats, bool a32) {
+#define CLS_RT3(TH, FR, ST) (a32 ? (const void*)place_tile_kernel<TH, FR, ST, true> : (const void*)place_tile_kernel<TH, FR, ST, false>)
+#define CLS_RT2(TH, FR) (stats ? CLS_RT3(TH, FR, true) : CLS_RT3(TH, FR, false))
+#define CLS_RT1(TH) (front == 2 ? CLS_RT2(TH, 2) : front == 1 ? CLS_RT2(TH, 1) : CLS_RT2(TH, 0))
     return threads == 512 ? CLS_RT1(512) : CLS_RT1(1024);
 #undef CLS_RT1
 #undef CLS_RT2
 #undef CLS_RT3
 }
+int tile_front(const DbDev& db) { return db.direct == nullptr ? 2 : db.canonical ? 1 : 0; }
 
 }  // namespace
 
-// binary FMT_SPLIT index with a direct table, pre-order indices in 24 bits
+// binary FMT_SPLIT index, pre-order indices in 24 bits; without a direct table (k > 15) the hashed front
 bool tile_usable(const DbDev& db) {
-    return db.format == FMT_SPLIT && db.binary_tree && db.direct != nullptr && db.n_nodes < RT_TIP_MASK && !tuning().no_tile;
+    return db.format == FMT_SPLIT && db.binary_tree && db.n_nodes < RT_TIP_MASK && !tuning().no_tile;
 }
 
 // Two configurations of the one kernel.  WHOLE: a read has the whole LDS of a CU (one 1024-thread workgroup per CU; as many
@@ -436,30 +508,36 @@ bool tile_usable(const DbDev& db) {
 // (passes over hash partitions) and a read with more entries than 12 bytes x 80 KB hold is handed to a WHOLE launch.
 TilePlan tile_plan(const DbDev& db, uint32_t want_kmers, uint32_t n_long, uint32_t n_cu) {
     TilePlan p{};
-    const bool canon = db.canonical != 0;
+    const bool hashed = tile_front(db) == 2, canon = !hashed && db.canonical != 0;
     const uint32_t want = canon ? want_kmers / 2 : want_kmers;  // lookups of the longest read (canonical: one per window)
     auto bases_of = [&](uint32_t look) { return (canon ? look : look / 2) + db.k; };
-    uint32_t look = want;
-    const size_t lds_max = 160 * 1024 - sizeof(RtSh) - 256;
-    if (rt_smem(look, bases_of(look), 2 * look, look) > lds_max) {  // as many lookups per read as 160 KB of LDS hold; longer reads: the workspace kernel
-        look = (uint32_t)((lds_max - 64 - 4ull * 8) / 12);
-        while (look > 64 && rt_smem(look, bases_of(look), 2 * look, look) > lds_max) look -= 64;
+    uint32_t look = std::min<uint32_t>(want, 32767u);  // weights are summed in 16-bit halves
+    const size_t lds_max = 160 * 1024 - 512;  // (the kernel's static LDS is 320 bytes: RtSh and the barrier reductions)
+    // as many lookups per read as 160 KB of LDS hold; longer reads: the workspace kernel.  Direct table: a word per lookup
+    // and the code set at two words per lookup in the front, 12 bytes per lookup in the descent.  Hashed: the read's two
+    // strands in ASCII and a set of at least 1.25 words per lookup; the descent holds as many entries as fit (a read
+    // with more of them -- its k-mers' tip sets hardly ever repeating from one window to the next -- spills).
+    auto set_of = [&](uint32_t l) { return hashed ? l + l / 4 : 2 * l; };
+    auto cap_of = [&](uint32_t l) { return hashed ? std::min<uint32_t>(l, (uint32_t)((lds_max - 16) / 12)) : l; };
+    if (rt_smem(look, bases_of(look), set_of(look), cap_of(look), hashed) > lds_max) {
+        if (!hashed) look = std::min<uint32_t>(look, (uint32_t)((lds_max - 64 - 4ull * 8) / 12));
+        while (look > 64 && rt_smem(look, bases_of(look), set_of(look), cap_of(look), hashed) > lds_max) look -= 64;
     }
-    look = std::min<uint32_t>(look, 32767u);  // weights are summed in 16-bit halves
     p.lookups = look;
     p.bases = bases_of(look);
-    p.smem = rt_smem(look, p.bases, 2 * look, look);
-    p.set_words = 2 * look;
+    p.cap_entries = cap_of(look);
+    p.set_words = hashed ? std::min<uint32_t>(2 * look, (uint32_t)((lds_max - 16 - rt_front_bytes(look, p.bases, 0, true)) / 4)) : 2 * look;
+    p.smem = rt_smem(look, p.bases, p.set_words, p.cap_entries, hashed);
     p.threads = 1024u;
     p.grid = std::max<uint32_t>(1, std::min<uint32_t>(n_long, n_cu));
     p.cap_kmers = canon ? 2 * look : look;
-    // the HALF configuration: what is left of 80 KB after the packed read and the word per lookup is the code set
+    // the HALF configuration: what is left of 80 KB after the read (and the word per lookup) is the code set
     const size_t half_max = 79 * 1024 - sizeof(RtSh) - 256;  // (two of them, their static LDS and the allocation granule inside 160 KB)
-    const size_t fixed = rt_front_bytes(look, p.bases, 0);
-    if (!tuning().tile_one_per_cu && fixed + 4 * 4096 <= half_max) {
-        p.half_set_words = (uint32_t)((half_max - fixed) / 4);
+    const size_t fixed = rt_front_bytes(look, p.bases, 0, hashed);
+    if (!tuning().tile_one_per_cu && fixed + (hashed ? 4ull * set_of(look) : 4ull * 4096) <= half_max) {
+        p.half_set_words = (uint32_t)std::min<size_t>((half_max - fixed) / 4, 2ull * look + 64);
         p.half_cap_entries = (uint32_t)(half_max / 12);
-        p.half_smem = rt_smem(look, p.bases, p.half_set_words, p.half_cap_entries);
+        p.half_smem = rt_smem(look, p.bases, p.half_set_words, p.half_cap_entries, hashed);
         p.half_grid = std::max<uint32_t>(1, std::min<uint32_t>(n_long, 2 * n_cu));
     }
     p.scratch_words = (uint64_t)rt_scratch_words(look) * ((uint64_t)p.half_grid + p.grid);  // per resident workgroup 12 bytes per lookup (L2-resident)
@@ -468,29 +546,32 @@ TilePlan tile_plan(const DbDev& db, uint32_t want_kmers, uint32_t n_long, uint32
 
 std::string tile_kernel_name(const DbDev& db, bool stats, uint32_t threads) {
     auto b = [](bool v) { return std::string(v ? "true" : "false"); };
-    return "place_tile_kernel<" + std::to_string(threads) + ", " + b(db.canonical != 0) + ", " + b(stats) + ", " + b(db.addr32 != 0) + ">";
+    return "place_tile_kernel<" + std::to_string(threads) + ", " + std::to_string(tile_front(db)) + ", " + b(stats) + ", " + b(db.addr32 != 0) + ">";
 }
 
 void tile_launch(const DbDev& db, const PlaceParams& prm, const TilePlan& p, bool stats, const uint8_t* d_bases, const uint64_t* d_offsets,
                  const uint32_t* list, const uint32_t* list_len, cls_placement* d_out, cls_query_stats* d_stats, uint32_t* spill_list,
                  uint32_t* spill_len, uint32_t* scratch, uint32_t* big_list, uint32_t* big_len, hipStream_t stream) {
     uint32_t max_lookups = p.lookups, max_bases = p.bases;
-    auto launch = [&](uint32_t threads, uint32_t grid, size_t smem, uint32_t set_words, uint32_t cap_entries, const uint32_t* lst, const uint32_t* len, uint32_t* gws) {
-        const void* kfn = tile_kernel(threads, db.canonical != 0, stats, db.addr32 != 0);
+    auto launch = [&](uint32_t threads, uint32_t grid, size_t smem, uint32_t set_words, uint32_t cap_entries, const uint32_t* lst, const uint32_t* len, uint32_t* gws, bool last) {
+        const void* kfn = tile_kernel(threads, tile_front(db), stats, db.addr32 != 0);
         (void)hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         // the code set: every code in one pass at load <= 0.5 (knobs: fewer words / codes per pass -- tests)
         if (tuning().tile_set_words > 0) set_words = std::min<uint32_t>(set_words, (uint32_t)tuning().tile_set_words);
         uint32_t pass_codes = std::max<uint32_t>(1u, set_words / 2);
         if (tuning().tile_pass_codes > 0) pass_codes = (uint32_t)tuning().tile_pass_codes;
+        // a read with more entries than the configuration holds: HALF hands it to the WHOLE launch, WHOLE (hashed front only) to the workspace kernel
+        uint32_t* over_list = last ? spill_list : big_list;
+        uint32_t* over_len = last ? spill_len : big_len;
         void* args[] = {(void*)&db, (void*)&prm, (void*)&d_bases, (void*)&d_offsets, (void*)&lst, (void*)&len, (void*)&d_out, (void*)&d_stats,
                         (void*)&max_lookups, (void*)&max_bases, (void*)&pass_codes, (void*)&set_words, (void*)&spill_list, (void*)&spill_len,
-                        (void*)&cap_entries, (void*)&gws, (void*)&big_list, (void*)&big_len};
+                        (void*)&cap_entries, (void*)&gws, (void*)&over_list, (void*)&over_len};
         (void)hipLaunchKernel(kfn, dim3(grid), dim3(threads), args, smem, stream);
     };
     if (p.half_grid) {
-        launch(512u, p.half_grid, p.half_smem, p.half_set_words, p.half_cap_entries, list, list_len, scratch);
-        launch(1024u, p.grid, p.smem, p.set_words, p.lookups, big_list, big_len, scratch + (uint64_t)rt_scratch_words(p.lookups) * p.half_grid);  // the reads with more entries
-    } else launch(1024u, p.grid, p.smem, p.set_words, p.lookups, list, list_len, scratch);
+        launch(512u, p.half_grid, p.half_smem, p.half_set_words, p.half_cap_entries, list, list_len, scratch, false);
+        launch(1024u, p.grid, p.smem, p.set_words, p.cap_entries, big_list, big_len, scratch + (uint64_t)rt_scratch_words(p.lookups) * p.half_grid, true);  // the reads with more entries
+    } else launch(1024u, p.grid, p.smem, p.set_words, p.cap_entries, list, list_len, scratch, true);
 }
 
 }  // namespace cls

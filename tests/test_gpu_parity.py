@@ -355,6 +355,38 @@ def test_long_reads_lds_tiled_kernel_and_its_spill_path():
         engine.set_tuning("no_tile", 0)
 
 
+@pytest.mark.parametrize("k,deep", [(16, 0), (21, 1), (35, 0)])
+def test_long_reads_lds_tiled_kernel_hashed_front(k, deep):
+    """k > 15 (no direct table; the reference's documented k is 35): the LDS-tiled kernel hashes every k-mer of both
+    strands (MurmurHash3, kmers_map.rs:157-159), probes the table and applies the minimizer-bucket filter
+    (kmers_map.rs:273-311).  Same records with the kernel switched off (workspace kernel) and against the oracle."""
+    s = SynthDb(150, 11000, k, 4, deep=deep)
+    rng = np.random.default_rng(45 + k)
+    bases, offsets = ragged_reads(rng, s, 48, 4200, 10800, lower_frac=0.05)
+    with engine.PlacementDb(s.flat, device=0) as db:
+        assert (db.info.format, db.info.binary_tree, db.info.direct_table) == (1, 1, 0)
+        db.set_max_read_len(10800)
+        assert db.kernel_name().startswith("place_tile_kernel<512, 2,") or db.kernel_name().startswith("place_tile_kernel<1024, 2,")
+    for flat in (s.flat, truncate_random_sets(s.flat, 0.02, seed=5)):
+        for kw in (dict(), dict(remove_intersection=True), dict(max_iterations=6)):
+            got = _check(flat, bases, offsets, kw, threads=16)
+        assert (got["status"] != _abi.ERR_READ_TOO_LONG).all()
+    engine.set_tuning("no_tile", 1)
+    try:
+        off = _check(flat, bases, offsets, kw, threads=16)
+        assert len(records_equal(off, got)) == 0
+    finally:
+        engine.set_tuning("no_tile", 0)
+    for pass_codes, set_words in ((1 << 30, 4096), (1024, 4096)):  # the spill path and the passes over hash partitions (keys: table slots)
+        engine.set_tuning("tile_pass_codes", pass_codes)
+        engine.set_tuning("tile_set_words", set_words)
+        try:
+            assert len(records_equal(_check(flat, bases, offsets, kw, threads=16), got)) == 0
+        finally:
+            engine.set_tuning("tile_pass_codes", 0)
+            engine.set_tuning("tile_set_words", 0)
+
+
 @pytest.mark.parametrize("k,collapse,trunc", [(12, 0.0, False), (10, 0.4, False), (11, 0.0, True)])
 def test_slim_and_denormalised_direct_tables_agree(k, collapse, trunc):
     """For k <= 12 the wave-per-read kernels read a denormalised 16-byte direct table (set record inside the entry);
