@@ -275,7 +275,7 @@ def main():
         first = rank * per_gpu
     cfg["n_reads"] = per_gpu
     if args.config == "G35":
-        engine.set_tuning("time_class", 2)  # 1.9 kb reads: the workgroup-per-read kernel is the one to time and name
+        engine.set_tuning("time_class", 2)  # 1.9 kb reads: the kernel of the gene-length classes (the LDS-tiled one) is the one to time and name
     t0 = time.time()
     synth = None
     if world == 1 or rank == 0:
@@ -308,7 +308,7 @@ def main():
     t0 = time.time()
     db = engine.PlacementDb(flat, device=local_rank)
     create_s = time.time() - t0
-    if cfg["read_len"] > 4096:
+    if cfg["read_len"] > 320:  # (beyond the wave-per-read kernels: the launch configuration follows the longest read)
         db.set_max_read_len(cfg["read_len"])
     # this rank's shard of the global read stream (seed 3); every rank allocates per_gpu records so that the
     # gather has one shape (the last shard of a strong-scaling split may be shorter: its tail stays zero)

@@ -9,12 +9,22 @@
 namespace cls {
 
 // LDS-tiled long-read kernel (cls_tile.hip): binary FMT_SPLIT index with a direct table.
-struct TilePlan {
-    uint32_t threads, lookups, bases, cap_kmers, grid, set_words, cap_entries;  // the configuration that gives a read a whole CU's LDS
+// One launch of the LDS-tiled kernel (cls_tile.hip): `threads` x `grid`, a read of up to `cap_kmers` k-mers (`lookups` table
+// lookups, `bases` bases) per workgroup.
+struct TileCfg {
+    uint32_t threads, grid, lookups, bases, cap_kmers, set_words, cap_entries;
     size_t smem;
-    uint32_t half_grid, half_set_words, half_cap_entries;          // two workgroups per CU (half_grid == 0: not for reads this long)
-    size_t half_smem;
-    uint64_t scratch_words;                                        // global scratch of the resident workgroups
+    uint64_t scratch_off;   // the resident workgroups' slots of the global scratch (u32 words into the tile scratch)
+};
+// The reads of the LDS-tiled kernel are binned by k-mer count into up to three SHARED launches (8, 4, 2 workgroups per CU: 128,
+// 256, 512 threads) and the WHOLE one (a read has the CU's LDS to itself: 1024 threads), which also takes the reads whose
+// entries overflow a shared launch's LDS.
+constexpr int TILE_MAX_SUB = 3;
+struct TilePlan {
+    TileCfg sub[TILE_MAX_SUB];
+    uint32_t n_sub;
+    TileCfg whole;
+    uint64_t scratch_words;
 };
 
 // Grid sizes + scratch layout of one placement batch.
@@ -33,24 +43,23 @@ struct PlacePlan {
     uint64_t long_set;         // entries of the distinct-hit set (power of two)
     uint64_t long_stride_words;
     uint64_t long_off_words;
-    uint32_t grid_tile;        // workgroups of the LDS-tiled long-read class (0: none in this launch)
-    uint32_t tile_threads;     // 512 (two workgroups per CU) or 1024
-    uint32_t tile_lookups;     // table lookups per read its LDS holds
-    uint32_t tile_bases;       // bases per read its LDS holds
-    uint32_t tile_cap_kmers;   // the same as a k-mer count (classification bound)
-    size_t tile_smem;          // dynamic LDS of that kernel
-    TilePlan tile;             // the whole plan of that class (cls_tile.hip)
-    uint64_t tile_off_words;   // its scratch + the list of reads handed from the two-per-CU launch to the one-per-CU one
+    bool tiled;                // the launch has the LDS-tiled classes (cls_tile.hip)
+    bool time_tile;            // ... and its kernel is the one that is timed (a handle provisioned for reads beyond MAX_READ_KMERS, or CLS_TIME_CLASS=2)
+    TilePlan tile;
+    uint32_t tile_from;        // reads with more k-mers than this (and at most tile.whole.cap_kmers) are the LDS-tiled kernel's
+    uint32_t tile_name_threads; // the configuration that takes the longest read the launch is provisioned for (cls_db_kernel_name)
+    uint64_t tile_off_words;   // its scratch
     uint64_t ws_bytes;         // device scratch the launch needs
 };
 // LDS-tiled long-read kernel (cls_tile.hip): launch interface
 bool tile_usable(const DbDev& db);
-TilePlan tile_plan(const DbDev& db, uint32_t want_kmers, uint32_t n_long, uint32_t n_cu);
+TilePlan tile_plan(const DbDev& db, uint32_t from_kmers, uint32_t max_kmers, uint32_t n_reads, uint32_t n_cu);
 std::string tile_kernel_name(const DbDev& db, bool stats, uint32_t threads);
-// reads of `list` (device, *list_len of them) -> records; reads its code set cannot hold are appended to `spill_list`
+// reads of the shared launches' lists and of `big_list` (device) -> records; reads the kernel cannot hold (its code set, its
+// entries) are appended to `spill_list`
 void tile_launch(const DbDev& db, const PlaceParams& prm, const TilePlan& p, bool stats, const uint8_t* d_bases, const uint64_t* d_offsets,
-                 const uint32_t* list, const uint32_t* list_len, cls_placement* d_out, cls_query_stats* d_stats, uint32_t* spill_list,
-                 uint32_t* spill_len, uint32_t* scratch, uint32_t* big_list, uint32_t* big_len, hipStream_t stream);
+                 const uint32_t* const* sub_lists, const uint32_t* const* sub_lens, uint32_t* big_list, uint32_t* big_len,
+                 cls_placement* d_out, cls_query_stats* d_stats, uint32_t* spill_list, uint32_t* spill_len, uint32_t* scratch, hipStream_t stream);
 // `long_cap`: k-mer capacity wanted for reads beyond MAX_READ_KMERS (0 = refuse them), `n_long`: how many
 // such reads the batch may hold (bounds the number of workspace slices).
 PlacePlan plan_place(const DbDev& db, uint32_t n_reads, uint32_t n_cu, bool stats, uint32_t long_cap, uint32_t n_long);

@@ -2290,15 +2290,17 @@ __global__ __launch_bounds__(LONG_THREADS) void place_long_kernel(DbDev db, Plac
 // them (class lists in device memory; nothing returns to the host).  Reads no kernel can hold
 // get their record here.
 constexpr int CLASSIFY_THREADS = 256, CLASSIFY_PER_THREAD = 4;
-__global__ __launch_bounds__(CLASSIFY_THREADS) void classify_kernel(const uint64_t* __restrict__ offsets, uint32_t n_reads, uint32_t k,
-                                                                   uint32_t cap0, uint32_t cap1, uint32_t cap2, uint32_t cap3, uint32_t cap4,
-                                                                   uint32_t* __restrict__ list0, uint32_t* __restrict__ list1,
-                                                                   uint32_t* __restrict__ list2, uint32_t* __restrict__ list3, uint32_t* __restrict__ list4,
-                                                                   uint32_t* __restrict__ counts, cls_placement* __restrict__ out,
-                                                                   cls_query_stats* __restrict__ stats) {
+// class lists: 0, 1 the wave-per-read kernels; 2 the workgroup-per-read kernel; 3 .. 5 the shared launches of the LDS-tiled
+// kernel; 6 its launch that gives a read a whole CU (and the list the shared launches hand reads on to); 7 the workspace
+// kernel (and the list the LDS-tiled kernel spills to)
+constexpr int N_LISTS = 8;
+struct ClassCaps { uint32_t cap[N_LISTS]; };  // class c takes the reads of up to cap[c] k-mers that no class before it takes (0: not in this launch)
+__global__ __launch_bounds__(CLASSIFY_THREADS) void classify_kernel(const uint64_t* __restrict__ offsets, uint32_t n_reads, uint32_t k, ClassCaps caps,
+                                                                   uint32_t* __restrict__ lists, uint32_t* __restrict__ counts,
+                                                                   cls_placement* __restrict__ out, cls_query_stats* __restrict__ stats) {
     // a workgroup bins 1024 reads: positions inside the workgroup from LDS counters, ONE global atomic per class
-    __shared__ uint32_t s_cnt[5], s_base[5];
-    if (threadIdx.x < 5) s_cnt[threadIdx.x] = 0;
+    __shared__ uint32_t s_cnt[N_LISTS], s_base[N_LISTS];
+    if (threadIdx.x < N_LISTS) s_cnt[threadIdx.x] = 0;
     __syncthreads();
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t first = blockIdx.x * (CLASSIFY_THREADS * CLASSIFY_PER_THREAD) + threadIdx.x;
@@ -2312,12 +2314,10 @@ __global__ __launch_bounds__(CLASSIFY_THREADS) void classify_kernel(const uint64
         if (r < n_reads) {
             const uint64_t L = offsets[r + 1] - offsets[r];
             const uint64_t nk = L < k ? 0 : 2 * (L - k + 1);
-            if (nk <= cap0) cls_id[i] = 0;  // includes L < k: the kernel reports CLS_ERR_TOO_FEW_KMERS
-            else if (nk <= cap1) cls_id[i] = 1;
-            else if (nk <= cap2) cls_id[i] = 2;
-            else if (nk <= cap3) cls_id[i] = 3;  // cap3 = 0: no LDS-tiled long-read class in this launch
-            else if (nk <= cap4) cls_id[i] = 4;  // cap4 = 0: no workspace long-read class in this launch
-            else {
+            // (class 0 includes L < k: the kernel reports CLS_ERR_TOO_FEW_KMERS)
+#pragma unroll
+            for (int c = N_LISTS - 1; c >= 0; --c) if (nk <= caps.cap[c]) cls_id[i] = c;
+            if (cls_id[i] < 0) {
                 uint64_t* o = reinterpret_cast<uint64_t*>(out + r);
                 o[0] = CLS_ERR_READ_TOO_LONG; o[1] = 0; o[2] = 0;
                 if (stats) {
@@ -2327,7 +2327,7 @@ __global__ __launch_bounds__(CLASSIFY_THREADS) void classify_kernel(const uint64
             }
         }
 #pragma unroll
-        for (int c = 0; c < 5; ++c) {
+        for (int c = 0; c < N_LISTS; ++c) {
             const uint64_t m = __ballot(cls_id[i] == c);
             if (!m) continue;
             uint32_t base = 0;
@@ -2337,12 +2337,12 @@ __global__ __launch_bounds__(CLASSIFY_THREADS) void classify_kernel(const uint64
         }
     }
     __syncthreads();
-    if (threadIdx.x < 5) s_base[threadIdx.x] = s_cnt[threadIdx.x] ? atomicAdd(&counts[threadIdx.x], s_cnt[threadIdx.x]) : 0u;
+    if (threadIdx.x < N_LISTS) s_base[threadIdx.x] = s_cnt[threadIdx.x] ? atomicAdd(&counts[threadIdx.x], s_cnt[threadIdx.x]) : 0u;
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < CLASSIFY_PER_THREAD; ++i) {
         const int c = cls_id[i];
-        if (c >= 0) (c == 0 ? list0 : c == 1 ? list1 : c == 2 ? list2 : c == 3 ? list3 : list4)[s_base[c] + pos[i]] = first + i * CLASSIFY_THREADS;
+        if (c >= 0) lists[(size_t)c * n_reads + s_base[c] + pos[i]] = first + i * CLASSIFY_THREADS;
     }
 }
 
@@ -2435,12 +2435,12 @@ size_t blk_smem(const DbDev& db) {
 std::string dominant_kernel_name(const DbDev& db, bool stats, const PlacePlan* plan) {
     const std::string sl = std::to_string(CLS_SLOTS[0]) + ", " + std::to_string(set_bits_of(db, 0)) + ", " + (stats ? "true" : "false");
     auto b = [](bool v) { return std::string(v ? "true" : "false"); };
-    if ((!plan || !plan->grid_tile) && tuning().time_class == 2) {
+    if (plan && plan->time_tile) return tile_kernel_name(db, stats, plan->tile_name_threads);  // a launch provisioned for long reads (or a bench of gene-length reads): the LDS-tiled kernel is the one that is timed
+    if (tuning().time_class == 2) {
         const std::string bl = std::to_string(BLK_WAVES) + ", " + std::to_string(BLK_SLOTS) + ", " + std::to_string(BLK_SET_BITS) + ", " + b(stats);
         if (db.format == FMT_SPLIT) return "place_block_kernel<" + bl + ", " + b(db.binary_tree != 0) + ", true>";
         return "place_block_kernel<" + bl + ", " + b(db.max_nonleaf_arity <= 2) + ", false>";
     }
-    if (plan && plan->grid_tile) return tile_kernel_name(db, stats, plan->tile_threads);  // a launch provisioned for long reads: the LDS-tiled kernel is the one that is timed
     if (use_fast(db))
         return "place_fast_kernel<" + sl + ", " + b(fast_mode(db) == 2 || db.addr32) + ", " + std::to_string(fast_mode(db)) + ", " + b(!db.binary_tree) + ">";
     if (db.format == FMT_SPLIT) return "place_split_kernel<" + sl + ", " + b(!db.binary_tree) + ">";
@@ -2472,7 +2472,7 @@ PlacePlan plan_place(const DbDev& db, uint32_t n_reads, uint32_t n_cu, bool stat
     if (!child_in_lds(db)) child_words = std::max<uint64_t>(child_words, (uint64_t)p.grid_blk * 2 * child_ws_stride(db));
     // workspace (u32 words): [counts 16][list0 n][list1 n][list2 n][list3 n][list4 n][keys_in 2n][keys_out 2n][idx_in n][idx_out n][sort temp][child counters][long-read slices]
     p.ordered = use_order(db, n_reads);
-    uint64_t w = 16 + 5 * (uint64_t)n_reads;
+    uint64_t w = 16 + (uint64_t)N_LISTS * n_reads;
     w += w & 1;
     if (p.ordered) {
         // every resident workgroup (5 per CU at 96 VGPRs): since k-mers share split trees and the descent runs
@@ -2505,18 +2505,29 @@ PlacePlan plan_place(const DbDev& db, uint32_t n_reads, uint32_t n_cu, bool stat
     p.child_off_words = w;
     w += child_words;
     w += w & 1;
-    // LDS-tiled long-read class (binary FMT_SPLIT index with a direct table): as many lookups per read as 160 KB of LDS hold
-    if (long_cap > MAX_READ_KMERS && n_long && tile_usable(db)) {  // (cls_tile.hip)
-        const TilePlan tp = tile_plan(db, long_cap, n_long, n_cu);
-        p.tile = tp;
-        p.grid_tile = tp.half_grid ? tp.half_grid : tp.grid; p.tile_threads = tp.half_grid ? 512u : tp.threads; p.tile_lookups = tp.lookups;
-        p.tile_bases = tp.bases; p.tile_smem = tp.smem; p.tile_cap_kmers = tp.cap_kmers;
-        p.tile_off_words = w;
-        w += tp.scratch_words + n_reads;
-        w += w & 1;
+    // LDS-tiled classes (cls_tile.hip): every read beyond the wave-per-read kernels when the index has the shape for it --
+    // the workgroup-per-read kernel then only sees reads of an index that has not (measured on 300-leaf indexes, k = 15 / 35,
+    // binary / support-collapsed: 600 bp reads 3.3-4.9 M reads/s there against 23-48 M here, 1.9 kb 2.2-3.5 M against 7.6-17.6 M)
+    const uint32_t blk_cap = (uint32_t)(64 * BLK_WAVES * BLK_SLOTS);
+    p.tile_from = blk_cap;
+    const uint32_t long_want = n_long ? long_cap : 0u;  // (reads beyond MAX_READ_KMERS: only when the caller provisions for them)
+    if (tile_usable(db)) {
+        p.tile_from = tuning().tile_min_kmers > 0 ? std::min<uint32_t>(blk_cap, (uint32_t)tuning().tile_min_kmers) : (uint32_t)(64 * CLS_SLOTS[1]);
+        p.tile = tile_plan(db, p.tile_from, std::max<uint32_t>(long_want, MAX_READ_KMERS), n_reads, n_cu);
+        p.tiled = p.tile.whole.cap_kmers > p.tile_from;
     }
+    if (p.tiled) {
+        p.time_tile = long_want > MAX_READ_KMERS || tuning().time_class == 2;
+        p.tile_name_threads = p.tile.whole.threads;
+        const uint32_t longest = long_want ? long_want : MAX_READ_KMERS;
+        for (uint32_t i = p.tile.n_sub; i-- > 0;) if (p.tile.sub[i].cap_kmers >= longest) p.tile_name_threads = p.tile.sub[i].threads;
+        p.tile_off_words = w;
+        w += p.tile.scratch_words;
+        w += w & 1;
+    } else p.tile_from = blk_cap;
     // long-read class: per workgroup two state buffers (the distinct-hit set shares the second) + child counters
-    if (long_cap > MAX_READ_KMERS && n_long) {
+    if ((long_cap > MAX_READ_KMERS && n_long) || p.tiled) {  // (the LDS-tiled kernel spills to this one)
+        long_cap = std::max<uint32_t>(long_want, MAX_READ_KMERS);
         p.long_cap = long_cap;
         p.long_set = 1;
         while (p.long_set < 2 * (uint64_t)long_cap) p.long_set <<= 1;
@@ -2525,8 +2536,8 @@ PlacePlan plan_place(const DbDev& db, uint32_t n_reads, uint32_t n_cu, bool stat
         const uint64_t fit = std::max<uint64_t>(1, (2ull << 30) / (p.long_stride_words * 4));  // at most 2 GiB of slices
         // the kernel is bound by the latency of dependent reads and uses little LDS / few registers: several reads per CU
         const uint64_t per_cu_long = (uint64_t)std::max(1, tuning().long_blocks_per_cu);  // (1: 25.5 k reads/s of 10 kb, 2..8: 31 k)
-        p.grid_long = (uint32_t)std::min<uint64_t>({(uint64_t)n_long, (uint64_t)n_cu * per_cu_long, fit});
-        if (p.tile_cap_kmers >= long_cap) p.grid_long = std::min<uint32_t>(p.grid_long, 8u);  // only reads the tile kernel spills come here
+        p.grid_long = (uint32_t)std::min<uint64_t>({(uint64_t)std::max<uint32_t>(1u, n_long ? n_long : n_reads), (uint64_t)n_cu * per_cu_long, fit});
+        if (p.tiled && p.tile.whole.cap_kmers >= long_cap) p.grid_long = std::min<uint32_t>(p.grid_long, 8u);  // only reads the tile kernel spills come here
         p.long_off_words = w;
         w += p.long_stride_words * p.grid_long;
     }
@@ -2539,14 +2550,23 @@ hipError_t launch_place(const DbDev& db, const PlaceParams& prm, const PlacePlan
                         uint32_t* d_ws, hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop) {
     if (n_reads == 0) return hipSuccess;
     uint32_t* counts = d_ws;
-    uint32_t* lists[5] = {d_ws + 16, d_ws + 16 + n_reads, d_ws + 16 + 2 * (size_t)n_reads, d_ws + 16 + 3 * (size_t)n_reads, d_ws + 16 + 4 * (size_t)n_reads};
+    uint32_t* lists[N_LISTS];
+    for (int c = 0; c < N_LISTS; ++c) lists[c] = d_ws + 16 + (size_t)c * n_reads;
     uint32_t* child_ws = (child_ws_stride(db) && !child_in_lds(db)) ? d_ws + plan.child_off_words : nullptr;
     hipError_t e = hipMemsetAsync(counts, 0, 64, stream);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(classify_kernel, dim3((n_reads + CLASSIFY_THREADS * CLASSIFY_PER_THREAD - 1) / (CLASSIFY_THREADS * CLASSIFY_PER_THREAD)), dim3(CLASSIFY_THREADS), 0, stream, d_offsets, n_reads, db.k,
-                       (uint32_t)(64 * CLS_SLOTS[0]), (uint32_t)(64 * CLS_SLOTS[1]), (uint32_t)(64 * BLK_WAVES * BLK_SLOTS),
-                       plan.grid_tile ? plan.tile_cap_kmers : 0u, plan.long_cap,
-                       lists[0], lists[1], lists[2], lists[3], lists[4], counts, d_out, d_stats);
+    {
+        ClassCaps caps{};
+        caps.cap[0] = (uint32_t)(64 * CLS_SLOTS[0]); caps.cap[1] = (uint32_t)(64 * CLS_SLOTS[1]);
+        caps.cap[2] = plan.tiled ? plan.tile_from : (uint32_t)(64 * BLK_WAVES * BLK_SLOTS);
+        if (plan.tiled) {
+            for (uint32_t i = 0; i < plan.tile.n_sub; ++i) caps.cap[3 + i] = plan.tile.sub[i].cap_kmers;
+            caps.cap[6] = plan.tile.whole.cap_kmers;
+        }
+        caps.cap[7] = plan.long_cap;
+        hipLaunchKernelGGL(classify_kernel, dim3((n_reads + CLASSIFY_THREADS * CLASSIFY_PER_THREAD - 1) / (CLASSIFY_THREADS * CLASSIFY_PER_THREAD)), dim3(CLASSIFY_THREADS), 0, stream,
+                           d_offsets, n_reads, db.k, caps, lists[0], counts, d_out, d_stats);
+    }
     // CLS_PROFILE_STOP=1|2 truncates the split kernel after the match / state-init phase (timing
     // breakdowns only: the records it then writes are meaningless)
     const uint32_t profile_stop = (uint32_t)tuning().profile_stop;
@@ -2642,7 +2662,7 @@ hipError_t launch_place(const DbDev& db, const PlaceParams& prm, const PlacePlan
     };
     // the timed kernel (cls_db_kernel_time): the LDS-tiled long-read kernel in a launch provisioned for long reads,
     // else the wave-per-read kernel of the <= 320-k-mer class
-    const bool time_tile = plan.grid_tile != 0, time_blk = !time_tile && tuning().time_class == 2;  // (time_class 2: a bench of gene-length reads times the workgroup-per-read kernel)
+    const bool time_tile = plan.time_tile, time_blk = !time_tile && tuning().time_class == 2;  // (time_class 2: a bench of gene-length reads times the workgroup-per-read kernel)
     if (ev_start && !time_tile && !time_blk) (void)hipEventRecord(ev_start, stream);
     if (set_bits_of(db, 0) != CLS_SET_BITS[0]) launch_class(std::integral_constant<int, CLS_SLOTS[0]>{}, std::integral_constant<int, NARROW_CANON_BITS>{}, 0);
     else launch_class(std::integral_constant<int, CLS_SLOTS[0]>{}, std::integral_constant<int, CLS_SET_BITS[0]>{}, 0);
@@ -2650,7 +2670,7 @@ hipError_t launch_place(const DbDev& db, const PlaceParams& prm, const PlacePlan
     if (hipGetLastError() != hipSuccess) return hipErrorLaunchFailure;
     launch_class(std::integral_constant<int, CLS_SLOTS[1]>{}, std::integral_constant<int, CLS_SET_BITS[1]>{}, 1);
     if (hipGetLastError() != hipSuccess) return hipErrorLaunchFailure;
-    {   // class 2: one workgroup per read (the generic probe path, whatever the index format)
+    if (!plan.tiled || plan.tile_from > (uint32_t)(64 * CLS_SLOTS[1])) {   // class 2: one workgroup per read (the generic probe path, whatever the index format)
         const dim3 grid(plan.grid_blk), block(64 * BLK_WAVES);
         const uint32_t seq_cap = blk_seq_cap(db);
         const size_t smem = blk_smem(db);
@@ -2669,20 +2689,21 @@ hipError_t launch_place(const DbDev& db, const PlaceParams& prm, const PlacePlan
 #undef CLS_LAUNCH_BLK
         if (ev_stop && time_blk) (void)hipEventRecord(ev_stop, stream);
     }
-    if (plan.grid_tile) {  // class 3: long reads, every state in LDS; reads it cannot hold are appended to class 4's list
+    if (plan.tiled) {  // classes 3 .. 6: every state in LDS; reads the kernel cannot hold are appended to class 7's list
         if (hipGetLastError() != hipSuccess) return hipErrorLaunchFailure;
-        if (ev_start) (void)hipEventRecord(ev_start, stream);
-        uint32_t* tile_ws = d_ws + plan.tile_off_words;
-        tile_launch(db, prm, plan.tile, st, d_bases, d_offsets, lists[3], counts + 3, d_out, d_stats, lists[4], counts + 4,
-                    tile_ws, tile_ws + plan.tile.scratch_words, counts + 5, stream);
-        if (ev_stop) (void)hipEventRecord(ev_stop, stream);
+        if (ev_start && time_tile) (void)hipEventRecord(ev_start, stream);
+        const uint32_t* sub_lists[TILE_MAX_SUB] = {lists[3], lists[4], lists[5]};
+        const uint32_t* sub_lens[TILE_MAX_SUB] = {counts + 3, counts + 4, counts + 5};
+        tile_launch(db, prm, plan.tile, st, d_bases, d_offsets, sub_lists, sub_lens, lists[6], counts + 6, d_out, d_stats, lists[7], counts + 7,
+                    d_ws + plan.tile_off_words, stream);
+        if (ev_stop && time_tile) (void)hipEventRecord(ev_stop, stream);
     }
-    if (plan.grid_long) {  // class 4: reads beyond what the LDS holds (and every long read of the other index shapes): state in the workspace
+    if (plan.grid_long) {  // class 7: reads beyond what the LDS holds (and every long read of the other index shapes): state in the workspace
         if (hipGetLastError() != hipSuccess) return hipErrorLaunchFailure;
         uint32_t* lws = d_ws + plan.long_off_words;
 #define CLS_LAUNCH_LONG(SP, ST)                                                                                                 \
     hipLaunchKernelGGL((place_long_kernel<SP, ST>), dim3(plan.grid_long), dim3(LONG_THREADS), 0, stream, db, prm, d_bases, d_offsets, \
-                       lists[4], counts + 4, d_out, d_stats, lws, plan.long_stride_words, plan.long_cap, (uint32_t)plan.long_set,  \
+                       lists[7], counts + 7, d_out, d_stats, lws, plan.long_stride_words, plan.long_cap, (uint32_t)plan.long_set,  \
                        plan.long_arity)
         if (db.format == FMT_SPLIT) { if (st) CLS_LAUNCH_LONG(true, true); else CLS_LAUNCH_LONG(true, false); }
         else { if (st) CLS_LAUNCH_LONG(false, true); else CLS_LAUNCH_LONG(false, false); }

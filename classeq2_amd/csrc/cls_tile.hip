@@ -55,6 +55,9 @@ struct RtSh {
     uint32_t overflow;
     uint32_t ib;
     unsigned long long leafp;
+    uint32_t pu, n_pass;     // polytomy levels: running sums over the levels (a level takes the difference to what it saw before)
+    uint32_t best_row, n_best;
+    int32_t best_one, best_rest;
 };
 
 __host__ __device__ inline uint32_t rt_packed_words(uint32_t max_bases) { return ((max_bases + 15) / 16 + 2 + 3) & ~3u; }
@@ -62,13 +65,15 @@ __host__ __device__ inline uint32_t rt_seq_words(uint32_t max_bases) { return ((
 // Dynamic LDS: the FRONT holds the packed read, one word per lookup and the set of codes; the DESCENT, over the same
 // bytes, 12 bytes per entry.  The entries travel from the one to the other through the workgroup's slot of a global
 // scratch (L2-resident: 12 bytes x max_lookups per resident workgroup), so that neither phase pays for the other's LDS.
-__host__ __device__ inline uint32_t rt_scratch_words(uint32_t max_lookups) { return (3u * max_lookups + 1u) & ~1u; }  // a workgroup's slot: 12 bytes per lookup, 8-byte aligned
+__host__ __device__ inline uint32_t rt_scratch_words(uint32_t cap_entries) { return (3u * cap_entries + 1u) & ~1u; }  // a workgroup's slot: 12 bytes per entry, 8-byte aligned
 __host__ __device__ inline size_t rt_front_bytes(uint32_t max_lookups, uint32_t max_bases, uint32_t set_words, bool hashed) {
     return hashed ? 4ull * rt_seq_words(max_bases) + 4ull * set_words
                   : 4ull * rt_packed_words(max_bases) + 4ull * max_lookups + 4ull * set_words;
 }
-__host__ __device__ inline size_t rt_smem(uint32_t max_lookups, uint32_t max_bases, uint32_t set_words, uint32_t cap_entries, bool hashed) {
-    const size_t f = rt_front_bytes(max_lookups, max_bases, set_words, hashed), d = 12ull * cap_entries;
+// (polytomy trees: behind the entries the children's intervals and two counters per non-LEAF child of the clade at hand)
+__host__ __device__ inline uint32_t rt_child_words(uint32_t max_arity) { return 3u * max_arity + 4u; }
+__host__ __device__ inline size_t rt_smem(uint32_t max_lookups, uint32_t max_bases, uint32_t set_words, uint32_t cap_entries, bool hashed, uint32_t child_words) {
+    const size_t f = rt_front_bytes(max_lookups, max_bases, set_words, hashed), d = 12ull * cap_entries + 4ull * child_words;
     return (f > d ? f : d) + 16;
 }
 
@@ -85,8 +90,10 @@ __device__ __forceinline__ uint32_t rt_append(bool keep, uint32_t* counter, uint
 
 // FRONT: 0 = direct table, one lookup per k-mer; 1 = direct table of a strand-symmetric index, one lookup per window;
 // 2 = no direct table (k > 15): MurmurHash3 + hash-table probe per k-mer of both strands (kmers_map.rs:157-159, :273-311)
-template <int THREADS, int FRONT, bool STATS, bool ADDR32>
-__global__ __launch_bounds__(THREADS) void place_tile_kernel(DbDev db, PlaceParams prm, const uint8_t* __restrict__ bases,
+// POLY: the tree has clades that do not have exactly two children (support-collapsed trees): a level at such a clade walks
+// every entry's chain of occupied children (below)
+template <int THREADS, int FRONT, bool STATS, bool ADDR32, bool POLY>
+__global__ __launch_bounds__(THREADS, 4) void place_tile_kernel(DbDev db, PlaceParams prm, const uint8_t* __restrict__ bases,
                                                              const uint64_t* __restrict__ offsets, const uint32_t* __restrict__ list,
                                                              const uint32_t* __restrict__ list_len, cls_placement* __restrict__ out,
                                                              cls_query_stats* __restrict__ stats, uint32_t max_lookups, uint32_t max_bases,
@@ -102,9 +109,12 @@ __global__ __launch_bounds__(THREADS) void place_tile_kernel(DbDev db, PlacePara
     uint32_t* const cset = HASHED ? packed + rt_seq_words(max_bases) : wsid + max_lookups;  // the set of codes (HASHED: table slots; no word per lookup) that makes the k-mers distinct
     uint2* const ent = reinterpret_cast<uint2*>(smem);            // {LO = first tip << 8 | weight, HI = last tip << 8}; dead: {RT_DEAD_LO, 0}
     uint32_t* const xs = reinterpret_cast<uint32_t*>(ent + cap_entries);  // split record of the entry's set
+    uint32_t* const cpre = xs + cap_entries;                      // POLY: where each non-LEAF child of the clade at hand starts (and, one more, where the last ends)
+    uint32_t* const ccnt = cpre + db.max_nonleaf_arity + 2;       //       k-mers with a tip under the child
+    uint32_t* const conly = ccnt + db.max_nonleaf_arity + 1;      //       ... and under no other
     // this workgroup's slot of the global scratch: the entries as the front makes them
-    uint2* const g_ent = reinterpret_cast<uint2*>(gws + (size_t)blockIdx.x * rt_scratch_words(max_lookups));
-    uint32_t* const g_xs = reinterpret_cast<uint32_t*>(g_ent + max_lookups);
+    uint2* const g_ent = reinterpret_cast<uint2*>(gws + (size_t)blockIdx.x * rt_scratch_words(cap_entries));
+    uint32_t* const g_xs = reinterpret_cast<uint32_t*>(g_ent + cap_entries);
     const uint32_t tid = threadIdx.x, lane = tid & 63;
     const uint32_t k = db.k;
     const uint32_t kmask = HASHED ? 0u : (1u << (2 * (k & 15u))) - 1u;  // (direct table: k <= 15)
@@ -167,8 +177,8 @@ __global__ __launch_bounds__(THREADS) void place_tile_kernel(DbDev db, PlacePara
                 packed[w] = acc;
             }
         }
-        if (tid == 0) { sh.n_groups = 0; sh.n_m = 0; sh.n_root = 0; sh.overflow = 0; sh.ib = 0; sh.leafp = 0; }
-        (void)seq; (void)wsid;
+        if (tid == 0) { sh.n_groups = 0; sh.n_m = 0; sh.n_root = 0; sh.overflow = 0; sh.ib = 0; sh.leafp = 0; sh.pu = 0; sh.n_pass = 0; }
+        (void)seq; (void)wsid; (void)cpre; (void)ccnt; (void)conly;
         if constexpr (HASHED) for (uint32_t i = tid; i < set_words; i += THREADS) cset[i] = RT_SET_EMPTY;
         if (tid < 3) { sh.cnt[tid] = 0; sh.fin[tid] = 0; }
         if (__syncthreads_or(bad ? 1 : 0)) { put_stats(0, 0, 0, 0, 0); record(CLS_ERR_INVALID_BASE, 0, 0, 0, 0); continue; }
@@ -319,7 +329,7 @@ __global__ __launch_bounds__(THREADS) void place_tile_kernel(DbDev db, PlacePara
                 if (STATS) leafp_t += (uint64_t)w * sr[q].w;
                 const bool live = w != 0 && has_root && has_tips;
                 const uint32_t g = rt_append(live, &sh.n_groups, lane);
-                if (live) {
+                if (live && g < cap_entries) {  // (a read with more entries than the launch holds is handed on below)
                     g_ent[g] = uint2{((sr[q].y & RT_TIP_MASK) << 8) | w, (sr[q].z & RT_TIP_MASK) << 8};
                     g_xs[g] = sr[q].x;
                 }
@@ -377,8 +387,11 @@ __global__ __launch_bounds__(THREADS) void place_tile_kernel(DbDev db, PlacePara
         // Every thread owns the same entries at every level (j = tid, tid + THREADS, ...): what it lists it settles and
         // counts itself, no barrier between those.  Both children's node records arrive a level ahead (one 64-byte
         // scalar load per level).
-        snode_pair_t C = load_node_pair(db.nodes, P.s[2]);  // (a binary tree: the root has its two children in consecutive rows)
-        if (STATS && tid == 0) ib += 64;
+        snode_pair_t C{};
+        if (!POLY || (P.s[7] >> 8) == 2) {
+            C = load_node_pair(db.nodes, P.s[2]);  // (a clade's non-LEAF children first, all in consecutive rows)
+            if (STATS && tid == 0) ib += 64;
+        }
         // exact share of this thread's settled entries against split a1n: k-mers with a tip before it | at or after it << 16
         auto count = [&](uint32_t a1ns) {
             uint32_t da = 0, db_ = 0;
@@ -391,11 +404,133 @@ __global__ __launch_bounds__(THREADS) void place_tile_kernel(DbDev db, PlacePara
             return da | (db_ << 16);
         };
         uint32_t dd = P.s[3] ? count(P.s[6] << 8) : 0u;
+        uint32_t pu_seen = 0, n_pass_seen = 0;  // (POLY: sh.pu, sh.n_pass as of the last polytomy level)
         int32_t iteration = 0;
         for (;;) {
             ++iteration;
             if (iteration > prm.max_iterations) { record(CLS_ERR_MAX_ITER, 0, 0, (uint32_t)iteration, 0); break; }
             const uint32_t m = P.s[3];
+            if (POLY && (P.s[7] >> 8) != 2) {
+                // ---- a clade that does not have exactly two children (polytomy after support collapse) --------------------
+                // The Cartesian tree of a set's tips breaks ties to the left, so the splits between an entry's occupied
+                // children form a right-going chain: every entry walks ITS OWN chain (the child under its first tip by binary
+                // search over the children's intervals, then one 8-byte read -- the right half of its split record: "the first
+                // tip beyond this child, the split of the rest" -- per further occupied child), adding its weight to the
+                // per-child counters in LDS.  Nothing is written to the entry: whichever child wins, `enter` below walks
+                // the (L2-warm) chain up to it.  (one, rest), place_sequence.rs:369-395, with |R_c| = |U| - |only_c| and
+                // |R_c \ K_c| = |U| - |K_c|.
+                const DNode* __restrict__ nodes = db.nodes;
+                const uint32_t fc = P.s[2];
+                uint32_t last_end = 0;
+                if (m) { const snode_t Lc = load_node(nodes, fc + m - 1); last_end = Lc.s[0] + Lc.s[1]; }  // the non-LEAF children come first, back to back
+                for (uint32_t i = tid; i < m; i += THREADS) { ccnt[i] = 0; conly[i] = 0; cpre[i] = nodes[fc + i].pre; if (STATS) ib += 4; }
+                if (tid == 0) { cpre[m] = last_end; sh.n_best = 0; if (STATS && m) ib += 32; }
+                __syncthreads();
+                if (tid == 0) sh.cnt[((uint32_t)iteration + 2u) % 3u] = 0;  // (the binary levels' rotation goes on through this level)
+                uint32_t u_t = 0;
+                for (uint32_t j = tid; j < n_groups; j += THREADS) {
+                    const uint2 e = ent[j];
+                    uint32_t v = e.x >> 8, xx = xs[j];
+                    const uint32_t vh = e.y >> 8, w = e.x & 0xFFu;
+                    uint32_t nin = 0, which = 0;
+                    while (v < last_end) {  // v lies under exactly one non-LEAF child: the last one that starts at or before it (a dead entry: v = 2^24 - 1)
+                        uint32_t lo_ = 0, hi_ = m;
+                        while (hi_ - lo_ > 1) { const uint32_t mid = (lo_ + hi_) >> 1; if (cpre[mid] <= v) lo_ = mid; else hi_ = mid; }
+                        const uint32_t c_end = cpre[lo_ + 1];  // (back to back: the next child starts where this one ends)
+                        atomicAdd(&ccnt[lo_], w);
+                        if (nin == 0) which = lo_;
+                        if (nin < 2) ++nin;
+                        if (vh < c_end) break;  // no tip beyond this child
+                        const uint2 h = ld_half<ADDR32>(half, xx, 1u);
+                        if (STATS) ib += 8;
+                        v = h.x; xx = h.y;
+                    }
+                    if (nin == 1) atomicAdd(&conly[which], w);
+                    u_t += nin ? w : 0u;
+                }
+                {
+                    const uint32_t a = wave_sum(u_t);
+                    if (lane == 0 && a) atomicAdd(&sh.pu, a);
+                }
+                __syncthreads();
+                const uint32_t U = sh.pu - pu_seen;
+                pu_seen += U;
+                for (uint32_t ci = tid; ci < m; ci += THREADS) {
+                    const uint32_t cn = ccnt[ci], on = conly[ci];
+                    if (!cn) continue;  // K_c empty: not a candidate (:329)
+                    const int32_t one = (int32_t)(rm ? on : cn), rest = (int32_t)(rm ? U - cn : U - on);
+                    if (one <= rest) continue;  // :411-417
+                    if (atomicAdd(&sh.n_pass, 1u) == n_pass_seen) { sh.best_row = fc + ci; sh.best_one = one; sh.best_rest = rest; sh.n_best = 1; }
+                }
+                __syncthreads();
+                const uint32_t n_pass = sh.n_pass - n_pass_seen;
+                n_pass_seen += n_pass;
+                if (n_pass > 1) {  // (cannot happen: |K_c| + |only_c| > |U| holds for at most one child; kept for fidelity with :519-599)
+                    if (tid == 0) {
+                        uint32_t np = 0, nb = 0;
+                        int32_t bd = 0;
+                        for (uint32_t ci = 0; ci < m; ++ci) {
+                            const uint32_t cn = ccnt[ci], on = conly[ci];
+                            if (!cn) continue;
+                            const int32_t one = (int32_t)(rm ? on : cn), rest = (int32_t)(rm ? U - cn : U - on);
+                            if (one <= rest) continue;
+                            const int32_t diff = one - rest;
+                            if (np == 0 || diff > bd) { bd = diff; nb = 1; sh.best_row = fc + ci; sh.best_one = one; sh.best_rest = rest; }
+                            else if (diff == bd) ++nb;
+                            ++np;
+                        }
+                        sh.n_best = nb;
+                    }
+                    __syncthreads();
+                }
+                const uint64_t pid = ((uint64_t)P.s[5] << 32) | P.s[4];
+                if (n_pass == 0) {
+                    if (iteration == 1) record(CLS_UNCLASSIFIABLE_LEVEL1, 0, 0, 1, 0);
+                    else record(CLS_MAX_RESOLUTION, 0, 0, (uint32_t)iteration, pid);
+                    break;
+                }
+                if (n_pass > 1 && sh.n_best != 1) { record(CLS_INCONCLUSIVE, (int32_t)n_pass, 0, (uint32_t)iteration, pid); break; }
+                const uint32_t best_row = sh.best_row;
+                const int32_t best_one = sh.best_one, best_rest = sh.best_rest;
+                P = load_node(nodes, best_row);
+                if (STATS && tid == 0) ib += 32;
+                if (P.s[3] == 0) {
+                    record(CLS_IDENTITY_FOUND, best_one, best_rest, (uint32_t)iteration, ((uint64_t)P.s[5] << 32) | P.s[4]);
+                    break;
+                }
+                if ((P.s[7] >> 8) == 2) { C = load_node_pair(nodes, P.s[2]); if (STATS && tid == 0) ib += 64; }
+                // enter the chosen child [c0, c_end): step past the occupied children before it, keep the part inside it (an
+                // entry whose tip IS the child has nothing below it), and count against the split of the child's children
+                const uint32_t c0 = P.s[0], c_end = c0 + P.s[1], a1ns = P.s[6] << 8;
+                uint32_t da = 0, db_ = 0;
+                for (uint32_t j = tid; j < n_groups; j += THREADS) {
+                    uint2 e = ent[j];
+                    if (e.x == RT_DEAD_LO) continue;
+                    uint32_t v = e.x >> 8, vh = e.y >> 8, xx = xs[j];
+                    const uint32_t w = e.x & 0xFFu;
+                    bool dead = false, changed = false;
+                    while (v < c0) {
+                        if (vh < c0) { dead = true; break; }
+                        const uint2 h = ld_half<ADDR32>(half, xx, 1u);
+                        if (STATS) ib += 8;
+                        v = h.x; xx = h.y; changed = true;
+                    }
+                    if (!dead && v < c_end && v != c0) {  // a tip strictly below the chosen clade
+                        if (vh >= c_end) {                // ... and tips beyond it: keep the part inside
+                            const uint2 h = ld_half<ADDR32>(half, xx, 0u);
+                            if (STATS) ib += 8;
+                            vh = h.x; xx = h.y; changed = true;
+                        }
+                    } else dead = true;
+                    if (dead) { ent[j] = uint2{RT_DEAD_LO, 0u}; continue; }
+                    e = uint2{(v << 8) | w, vh << 8};
+                    if (changed) { ent[j] = e; xs[j] = xx; }
+                    da += e.x < a1ns ? w : 0u;
+                    db_ += e.y >= a1ns ? w : 0u;
+                }
+                dd = da | (db_ << 16);
+                continue;
+            }
             const uint32_t a0 = P.s[0] + 1, a1 = P.s[6];  // first child = [a0, a1), second = [a1, end of the parent)
             const uint32_t a0s = (a0 << 8) | 0xFFu, a1s = a1 << 8;
             // |K_a| - |K_b| over the workgroup (a LEAF child is not scored, :322-324)
@@ -438,8 +573,10 @@ __global__ __launch_bounds__(THREADS) void place_tile_kernel(DbDev db, PlacePara
                 record(CLS_IDENTITY_FOUND, (int32_t)(rm ? on : cn), (int32_t)(rm ? U - cn : U - on), (uint32_t)iteration, ((uint64_t)Pn.s[5] << 32) | Pn.s[4]);
                 break;
             }
-            C = load_node_pair(db.nodes, Pn.s[2]);  // its children: looked at after the next barrier
-            if (STATS && tid == 0) ib += 64;
+            if (!POLY || (Pn.s[7] >> 8) == 2) {
+                C = load_node_pair(db.nodes, Pn.s[2]);  // its children: looked at after the next barrier
+                if (STATS && tid == 0) ib += 64;
+            }
             // narrow the thread's entries to the chosen clade -- only one with a tip OUTSIDE it is touched: going left one
             // whose last tip lies at or after a1, going right one whose first tip lies before a1; it dies or, with tips on
             // both sides, becomes pending on its half -- and count them against the split of that clade's children
@@ -484,94 +621,118 @@ __global__ __launch_bounds__(THREADS) void place_tile_kernel(DbDev db, PlacePara
     }
 }
 
-const void* tile_kernel(uint32_t threads, int front, bool stats, bool a32) {
-#define CLS_RT3(TH, FR, ST) (a32 ? (const void*)place_tile_kernel<TH, FR, ST, true> : (const void*)place_tile_kernel<TH, FR, ST, false>)
+const void* tile_kernel(uint32_t threads, int front, bool stats, bool a32, bool poly) {
+#define CLS_RT4(TH, FR, ST, A) (poly ? (const void*)place_tile_kernel<TH, FR, ST, A, true> : (const void*)place_tile_kernel<TH, FR, ST, A, false>)
+#define CLS_RT3(TH, FR, ST) (a32 ? CLS_RT4(TH, FR, ST, true) : CLS_RT4(TH, FR, ST, false))
 #define CLS_RT2(TH, FR) (stats ? CLS_RT3(TH, FR, true) : CLS_RT3(TH, FR, false))
 #define CLS_RT1(TH) (front == 2 ? CLS_RT2(TH, 2) : front == 1 ? CLS_RT2(TH, 1) : CLS_RT2(TH, 0))
-    return threads == 512 ? CLS_RT1(512) : CLS_RT1(1024);
+    return threads == 128 ? CLS_RT1(128) : threads == 256 ? CLS_RT1(256) : threads == 512 ? CLS_RT1(512) : CLS_RT1(1024);
 #undef CLS_RT1
 #undef CLS_RT2
 #undef CLS_RT3
+#undef CLS_RT4
 }
 int tile_front(const DbDev& db) { return db.direct == nullptr ? 2 : db.canonical ? 1 : 0; }
 
 }  // namespace
 
-// binary FMT_SPLIT index, pre-order indices in 24 bits; without a direct table (k > 15) the hashed front
+// FMT_SPLIT index, pre-order indices in 24 bits; without a direct table (k > 15) the hashed front; clades with up to
+// RT_MAX_ARITY non-LEAF children (their counters sit in LDS behind the entries)
+constexpr uint32_t RT_MAX_ARITY = 1024;
 bool tile_usable(const DbDev& db) {
-    return db.format == FMT_SPLIT && db.binary_tree && db.n_nodes < RT_TIP_MASK && !tuning().no_tile;
+    return db.format == FMT_SPLIT && (db.binary_tree || db.max_nonleaf_arity <= RT_MAX_ARITY) && db.n_nodes < RT_TIP_MASK && !tuning().no_tile;
 }
 
-// Two configurations of the one kernel.  WHOLE: a read has the whole LDS of a CU (one 1024-thread workgroup per CU; as many
-// lookups as 160 KB hold, the code set in one pass).  HALF, when the longest read's front fits half a CU (two 512-thread
-// workgroups per CU, their dependent chains overlapping: 1.45x per read measured on 5 kb reads): the code set is smaller
-// (passes over hash partitions) and a read with more entries than 12 bytes x 80 KB hold is handed to a WHOLE launch.
-TilePlan tile_plan(const DbDev& db, uint32_t want_kmers, uint32_t n_long, uint32_t n_cu) {
+// Configurations of the one kernel.  WHOLE: a read has the whole LDS of a CU (one 1024-thread workgroup per CU; as many
+// lookups as 160 KB hold, the code set in one pass).  SHARED: 8, 4 or 2 workgroups per CU (128, 256, 512 threads: sixteen
+// wavefronts a CU either way, their dependent chains overlapping -- 2 per CU: 1.45x per read measured on 5 kb reads; 4 per CU
+// on 1.9 kb reads: 1.8x over 2), each for the reads whose front fits its share of the LDS -- what is left of the share after
+// the read (and the word per lookup) is the code set -- while the descent still holds an entry for every second lookup; a
+// read with more entries than that is handed to the WHOLE launch.
+TilePlan tile_plan(const DbDev& db, uint32_t from_kmers, uint32_t max_kmers, uint32_t n_reads, uint32_t n_cu) {
     TilePlan p{};
     const bool hashed = tile_front(db) == 2, canon = !hashed && db.canonical != 0;
-    const uint32_t want = canon ? want_kmers / 2 : want_kmers;  // lookups of the longest read (canonical: one per window)
+    const uint32_t per_look = canon ? 2u : 1u;  // k-mers a lookup stands for (canonical: one per window)
+    const uint32_t want = std::min<uint32_t>((max_kmers + per_look - 1) / per_look, 32767u);  // lookups of the longest read; weights are summed in 16-bit halves
     auto bases_of = [&](uint32_t look) { return (canon ? look : look / 2) + db.k; };
-    uint32_t look = std::min<uint32_t>(want, 32767u);  // weights are summed in 16-bit halves
+    const uint32_t cw = db.binary_tree ? 0u : rt_child_words(db.max_nonleaf_arity);
     const size_t lds_max = 160 * 1024 - 512;  // (the kernel's static LDS is 320 bytes: RtSh and the barrier reductions)
-    // as many lookups per read as 160 KB of LDS hold; longer reads: the workspace kernel.  Direct table: a word per lookup
-    // and the code set at two words per lookup in the front, 12 bytes per lookup in the descent.  Hashed: the read's two
-    // strands in ASCII and a set of at least 1.25 words per lookup; the descent holds as many entries as fit (a read
+    // WHOLE -- as many lookups per read as 160 KB of LDS hold; longer reads: the workspace kernel.  Direct table: a word per
+    // lookup and the code set at two words per lookup in the front, 12 bytes per lookup in the descent.  Hashed: the read's
+    // two strands in ASCII and a set of at least 1.25 words per lookup; the descent holds as many entries as fit (a read
     // with more of them -- its k-mers' tip sets hardly ever repeating from one window to the next -- spills).
     auto set_of = [&](uint32_t l) { return hashed ? l + l / 4 : 2 * l; };
-    auto cap_of = [&](uint32_t l) { return hashed ? std::min<uint32_t>(l, (uint32_t)((lds_max - 16) / 12)) : l; };
-    if (rt_smem(look, bases_of(look), set_of(look), cap_of(look), hashed) > lds_max) {
-        if (!hashed) look = std::min<uint32_t>(look, (uint32_t)((lds_max - 64 - 4ull * 8) / 12));
-        while (look > 64 && rt_smem(look, bases_of(look), set_of(look), cap_of(look), hashed) > lds_max) look -= 64;
+    auto cap_of = [&](uint32_t l) { return hashed ? std::min<uint32_t>(l, (uint32_t)((lds_max - 16 - 4ull * cw) / 12)) : l; };
+    uint32_t look = want;
+    if (rt_smem(look, bases_of(look), set_of(look), cap_of(look), hashed, cw) > lds_max) {
+        if (!hashed) look = std::min<uint32_t>(look, (uint32_t)((lds_max - 64 - 4ull * 8 - 4ull * cw) / 12));
+        while (look > 64 && rt_smem(look, bases_of(look), set_of(look), cap_of(look), hashed, cw) > lds_max) look -= 64;
     }
-    p.lookups = look;
-    p.bases = bases_of(look);
-    p.cap_entries = cap_of(look);
-    p.set_words = hashed ? std::min<uint32_t>(2 * look, (uint32_t)((lds_max - 16 - rt_front_bytes(look, p.bases, 0, true)) / 4)) : 2 * look;
-    p.smem = rt_smem(look, p.bases, p.set_words, p.cap_entries, hashed);
-    p.threads = 1024u;
-    p.grid = std::max<uint32_t>(1, std::min<uint32_t>(n_long, n_cu));
-    p.cap_kmers = canon ? 2 * look : look;
-    // the HALF configuration: what is left of 80 KB after the read (and the word per lookup) is the code set
-    const size_t half_max = 79 * 1024 - sizeof(RtSh) - 256;  // (two of them, their static LDS and the allocation granule inside 160 KB)
-    const size_t fixed = rt_front_bytes(look, p.bases, 0, hashed);
-    if (!tuning().tile_one_per_cu && fixed + (hashed ? 4ull * set_of(look) : 4ull * 4096) <= half_max) {
-        p.half_set_words = (uint32_t)std::min<size_t>((half_max - fixed) / 4, 2ull * look + 64);
-        p.half_cap_entries = (uint32_t)(half_max / 12);
-        p.half_smem = rt_smem(look, p.bases, p.half_set_words, p.half_cap_entries, hashed);
-        p.half_grid = std::max<uint32_t>(1, std::min<uint32_t>(n_long, 2 * n_cu));
+    TileCfg& W = p.whole;
+    W.threads = 1024u;
+    W.lookups = look;
+    W.bases = bases_of(look);
+    W.cap_entries = cap_of(look);
+    W.set_words = hashed ? std::min<uint32_t>(2 * look, (uint32_t)((lds_max - 16 - rt_front_bytes(look, W.bases, 0, true)) / 4)) : 2 * look;
+    W.smem = rt_smem(look, W.bases, W.set_words, W.cap_entries, hashed, cw);
+    W.grid = std::max<uint32_t>(1, std::min<uint32_t>(n_reads, n_cu));
+    W.cap_kmers = per_look * look;
+    // SHARED
+    uint32_t covered = from_kmers;  // reads of up to this many k-mers have their launch
+    for (uint32_t per_cu = tuning().tile_one_per_cu ? 0u : 8u; per_cu >= 2 && covered < W.cap_kmers; per_cu /= 2) {
+        const size_t share = (160 * 1024) / per_cu - 1024 - 320;  // (their static LDS and the allocation granule inside 160 KB)
+        auto fits = [&](uint32_t l) {
+            const uint32_t need_set = hashed ? set_of(l) : std::min<uint32_t>(2 * l, 4096u);
+            return rt_front_bytes(l, bases_of(l), need_set, hashed) + 16 <= share && 12ull * (l / 2) + 4ull * cw + 16 <= share;
+        };
+        uint32_t l = look;
+        while (l > 32 && !fits(l)) l -= 32;
+        if (!fits(l) || per_look * l <= covered) continue;
+        TileCfg& c = p.sub[p.n_sub++];
+        c.threads = 1024u / per_cu;
+        c.lookups = l;
+        c.bases = bases_of(l);
+        c.set_words = (uint32_t)std::min<size_t>((share - 16 - rt_front_bytes(l, c.bases, 0, hashed)) / 4, 2ull * l + 64);
+        c.cap_entries = std::min<uint32_t>(l, (uint32_t)((share - 16 - 4ull * cw) / 12));
+        c.smem = rt_smem(l, c.bases, c.set_words, c.cap_entries, hashed, cw);
+        c.grid = std::max<uint32_t>(1, std::min<uint32_t>(n_reads, per_cu * n_cu));
+        c.cap_kmers = covered = per_look * l;
     }
-    p.scratch_words = (uint64_t)rt_scratch_words(look) * ((uint64_t)p.half_grid + p.grid);  // per resident workgroup 12 bytes per lookup (L2-resident)
+    // per resident workgroup 12 bytes per entry (L2-resident)
+    for (uint32_t i = 0; i <= p.n_sub; ++i) {
+        TileCfg& c = i < p.n_sub ? p.sub[i] : p.whole;
+        c.scratch_off = p.scratch_words;
+        p.scratch_words += (uint64_t)rt_scratch_words(c.cap_entries) * c.grid;
+    }
     return p;
 }
 
 std::string tile_kernel_name(const DbDev& db, bool stats, uint32_t threads) {
     auto b = [](bool v) { return std::string(v ? "true" : "false"); };
-    return "place_tile_kernel<" + std::to_string(threads) + ", " + std::to_string(tile_front(db)) + ", " + b(stats) + ", " + b(db.addr32 != 0) + ">";
+    return "place_tile_kernel<" + std::to_string(threads) + ", " + std::to_string(tile_front(db)) + ", " + b(stats) + ", " + b(db.addr32 != 0) + ", " + b(!db.binary_tree) + ">";
 }
 
 void tile_launch(const DbDev& db, const PlaceParams& prm, const TilePlan& p, bool stats, const uint8_t* d_bases, const uint64_t* d_offsets,
-                 const uint32_t* list, const uint32_t* list_len, cls_placement* d_out, cls_query_stats* d_stats, uint32_t* spill_list,
-                 uint32_t* spill_len, uint32_t* scratch, uint32_t* big_list, uint32_t* big_len, hipStream_t stream) {
-    uint32_t max_lookups = p.lookups, max_bases = p.bases;
-    auto launch = [&](uint32_t threads, uint32_t grid, size_t smem, uint32_t set_words, uint32_t cap_entries, const uint32_t* lst, const uint32_t* len, uint32_t* gws, bool last) {
-        const void* kfn = tile_kernel(threads, tile_front(db), stats, db.addr32 != 0);
-        (void)hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+                 const uint32_t* const* sub_lists, const uint32_t* const* sub_lens, uint32_t* big_list, uint32_t* big_len,
+                 cls_placement* d_out, cls_query_stats* d_stats, uint32_t* spill_list, uint32_t* spill_len, uint32_t* scratch, hipStream_t stream) {
+    // `over`: where a read with more entries than the launch holds goes -- from a shared launch to the WHOLE one, from that
+    // (hashed front only) to the workspace kernel
+    auto launch = [&](const TileCfg& c, const uint32_t* lst, const uint32_t* len, uint32_t* over_list, uint32_t* over_len) {
+        const void* kfn = tile_kernel(c.threads, tile_front(db), stats, db.addr32 != 0, !db.binary_tree);
+        (void)hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c.smem);
+        uint32_t max_lookups = c.lookups, max_bases = c.bases, set_words = c.set_words, cap_entries = c.cap_entries;
+        uint32_t* gws = scratch + c.scratch_off;
         // the code set: every code in one pass at load <= 0.5 (knobs: fewer words / codes per pass -- tests)
         if (tuning().tile_set_words > 0) set_words = std::min<uint32_t>(set_words, (uint32_t)tuning().tile_set_words);
         uint32_t pass_codes = std::max<uint32_t>(1u, set_words / 2);
         if (tuning().tile_pass_codes > 0) pass_codes = (uint32_t)tuning().tile_pass_codes;
-        // a read with more entries than the configuration holds: HALF hands it to the WHOLE launch, WHOLE (hashed front only) to the workspace kernel
-        uint32_t* over_list = last ? spill_list : big_list;
-        uint32_t* over_len = last ? spill_len : big_len;
         void* args[] = {(void*)&db, (void*)&prm, (void*)&d_bases, (void*)&d_offsets, (void*)&lst, (void*)&len, (void*)&d_out, (void*)&d_stats,
                         (void*)&max_lookups, (void*)&max_bases, (void*)&pass_codes, (void*)&set_words, (void*)&spill_list, (void*)&spill_len,
                         (void*)&cap_entries, (void*)&gws, (void*)&over_list, (void*)&over_len};
-        (void)hipLaunchKernel(kfn, dim3(grid), dim3(threads), args, smem, stream);
+        (void)hipLaunchKernel(kfn, dim3(c.grid), dim3(c.threads), args, c.smem, stream);
     };
-    if (p.half_grid) {
-        launch(512u, p.half_grid, p.half_smem, p.half_set_words, p.half_cap_entries, list, list_len, scratch, false);
-        launch(1024u, p.grid, p.smem, p.set_words, p.cap_entries, big_list, big_len, scratch + (uint64_t)rt_scratch_words(p.lookups) * p.half_grid, true);  // the reads with more entries
-    } else launch(1024u, p.grid, p.smem, p.set_words, p.cap_entries, list, list_len, scratch, true);
+    for (uint32_t i = 0; i < p.n_sub; ++i) launch(p.sub[i], sub_lists[i], sub_lens[i], big_list, big_len);
+    launch(p.whole, big_list, big_len, spill_list, spill_len);
 }
 
 }  // namespace cls

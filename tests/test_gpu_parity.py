@@ -128,9 +128,39 @@ def test_long_reads_workspace_kernel(k, collapse, drop, deep):
     rng = np.random.default_rng(33)
     bases, offsets = ragged_reads(rng, s, 40, 4200, 11000, lower_frac=0.05)
     got = None
-    for kw in (dict(), dict(remove_intersection=True, max_iterations=9)):
-        got = _check(flat, bases, offsets, kw, threads=16)
+    engine.set_tuning("no_tile", 1)
+    try:
+        for kw in (dict(), dict(remove_intersection=True, max_iterations=9)):
+            got = _check(flat, bases, offsets, kw, threads=16)
+    finally:
+        engine.set_tuning("no_tile", 0)
     assert (got["status"] != _abi.ERR_READ_TOO_LONG).all()
+
+
+@pytest.mark.parametrize("k,collapse,deep,leaves", [(15, 0.3, 0, 200), (12, 0.6, 1, 120), (20, 0.5, 1, 90), (35, 0.3, 0, 200), (13, 0.85, 0, 150)])
+def test_long_reads_lds_tiled_kernel_polytomy_levels(k, collapse, deep, leaves):
+    """Support-collapsed trees (the reference's default build collapses weakly supported clades): at a clade that does not
+    have exactly two children the LDS-tiled kernel walks every entry's chain of occupied children and keeps per-child
+    counters in LDS (place_sequence.rs:369-417, :519-599); binary levels in between take the two-counter path.  Direct and
+    hashed front, both remove_intersection settings, a low iteration cap; same records with the kernel switched off."""
+    s = SynthDb(leaves, 11000, k, 4, collapse_prob=collapse, deep=deep)
+    rng = np.random.default_rng(70 + k)
+    bases, offsets = ragged_reads(rng, s, 48, 4200, 10800, lower_frac=0.05)
+    with engine.PlacementDb(s.flat, device=0) as db:
+        assert (db.info.format, db.info.binary_tree) == (1, 0)
+        assert db.info.max_nonleaf_arity > (4 if collapse > 0.8 else 2)
+        db.set_max_read_len(10800)
+        assert db.kernel_name().startswith("place_tile_kernel<") and db.kernel_name().endswith(", true>")
+    got = {}
+    for kw in (dict(), dict(remove_intersection=True), dict(max_iterations=4)):
+        got[tuple(kw)] = _check(s.flat, bases, offsets, kw, threads=16)
+    assert (got[()]["status"] != _abi.ERR_READ_TOO_LONG).all()
+    engine.set_tuning("no_tile", 1)
+    try:
+        for kw in (dict(), dict(remove_intersection=True)):
+            assert len(records_equal(_check(s.flat, bases, offsets, kw, threads=16), got[tuple(kw)])) == 0
+    finally:
+        engine.set_tuning("no_tile", 0)
 
 
 @pytest.mark.parametrize("k,collapse", [(9, 0.0), (9, 0.3), (17, 0.0)])
@@ -180,13 +210,23 @@ def test_long_and_short_reads_in_one_batch():
 
 @pytest.mark.parametrize("k,collapse,drop", [(12, 0.0, 0.0), (35, 0.0, 0.0), (11, 0.4, 0.0), (10, 0.3, 0.2), (16, 0.0, 0.15)])
 def test_gene_length_reads_workgroup_kernel(k, collapse, drop):
-    """Reads of 600..3500 bp (marker-gene queries): the workgroup-per-read kernels, every index format."""
+    """Reads of 600..3500 bp (marker-gene queries), every index format: the LDS-tiled kernel's shared launches (8, 4, 2
+    workgroups per CU by read length) where the index has the shape for it, the workgroup-per-read kernel where it has not
+    -- and with the LDS-tiled kernel switched off."""
     s = SynthDb(150, 4000, k, 4, collapse_prob=collapse)
     flat = drop_random_nodes(s.flat, drop, seed=8) if drop else s.flat
     rng = np.random.default_rng(21)
-    bases, offsets = ragged_reads(rng, s, 120, 600, 3500, lower_frac=0.05)
+    bases, offsets = ragged_reads(rng, s, 120, 300, 3500, lower_frac=0.05)
+    got = {}
     for kw in (dict(), dict(remove_intersection=True, max_iterations=6)):
-        _check(flat, bases, offsets, kw, threads=16)
+        got[tuple(kw)] = _check(flat, bases, offsets, kw, threads=16)
+    for knob, value in (("no_tile", 1), ("tile_one_per_cu", 1), ("tile_min_kmers", 2000)):
+        engine.set_tuning(knob, value)
+        try:
+            for kw in (dict(), dict(remove_intersection=True, max_iterations=6)):
+                assert len(records_equal(_check(flat, bases, offsets, kw, threads=16), got[tuple(kw)])) == 0
+        finally:
+            engine.set_tuning(knob, 0)
 
 
 @pytest.mark.parametrize("collapse", [0.0, 0.4])
