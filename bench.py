@@ -308,8 +308,7 @@ def main():
     t0 = time.time()
     db = engine.PlacementDb(flat, device=local_rank)
     create_s = time.time() - t0
-    if cfg["read_len"] > 320:  # (beyond the wave-per-read kernels: the launch configuration follows the longest read)
-        db.set_max_read_len(cfg["read_len"])
+    db.set_max_read_len(cfg["read_len"])  # the launch follows the longest read: classes beyond it are not launched
     # this rank's shard of the global read stream (seed 3); every rank allocates per_gpu records so that the
     # gather has one shape (the last shard of a strong-scaling split may be shorter: its tail stays zero)
     if world > 1:

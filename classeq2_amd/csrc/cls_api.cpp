@@ -259,7 +259,7 @@ extern "C" int cls_db_create(const cls_db_desc* d, int device, cls_db** out) {
         i.table_slots = E.table.size();
         i.postings_words = E.postings.size();
         i.hbm_bytes = E.nodes.size() * sizeof(cls::DNode) + E.table.size() * sizeof(cls::Slot) + (E.postings.size() + E.postings2.size()) * 4 + E.bucket_key.size() * 8 + E.direct.size() * 4 + E.direct16.size() * 4 + (E.sets.size() + E.sets2.size()) * sizeof(cls::SetRec);
-        i.max_read_kmers = (uint32_t)std::max<uint64_t>(cls::MAX_READ_KMERS, 2 * db->max_read_len);
+        i.max_read_kmers = db->max_read_len ? (uint32_t)std::max<uint64_t>(320, 2 * db->max_read_len) : cls::MAX_READ_KMERS;
         i.device = device;
         i.format = E.format;
         i.binary_tree = E.strictly_binary ? 1u : 0u;
@@ -586,13 +586,14 @@ static int place_host(cls_db* db, const char* bases, const uint64_t* offsets, ui
             std::vector<uint64_t>& ro = rel[turn];
             ro.resize((size_t)cnt + 1);
             for (uint32_t i = 0; i <= cnt; ++i) ro[i] = offsets[first + i] - offsets[first];
-            // reads beyond the register-resident kernels: provision exactly what this chunk needs
-            uint64_t longest = 0;
-            uint32_t n_long = 0;
+            // provision exactly what this chunk needs: the classes beyond its longest read are not launched
+            uint64_t longest = 1;
+            uint32_t n_long = 1;
             for (uint32_t i = 0; i < cnt; ++i) {
                 const uint64_t len = ro[i + 1] - ro[i];
                 const uint64_t nk = len < db->dev.k ? 0 : 2 * (len - db->dev.k + 1);
-                if (nk > cls::MAX_READ_KMERS) { ++n_long; longest = std::max(longest, std::min(len, HARD_MAX_READ_LEN)); }
+                longest = std::max(longest, std::min(len, HARD_MAX_READ_LEN));
+                if (nk > cls::MAX_READ_KMERS) ++n_long;
             }
             if (nbytes) CLS_TRY(hipMemcpyAsync(c.d_bases, bases + offsets[first], nbytes, hipMemcpyHostToDevice, c.stream));
             CLS_TRY(hipMemcpyAsync(c.d_off, ro.data(), ((size_t)cnt + 1) * 8, hipMemcpyHostToDevice, c.stream));
@@ -684,12 +685,13 @@ extern "C" int cls_place_fasta_text(cls_db* db, const char* text, size_t len, co
         if (n) CLS_TRY(hipMalloc(&d_out, (size_t)std::min(n, max_reads) * sizeof(cls_placement)));
         for (uint32_t first = 0; first < n; first += max_reads) {
             const uint32_t cnt = std::min(max_reads, n - first);
-            uint64_t longest = 0;
-            uint32_t n_long = 0;
+            uint64_t longest = 1;  // (the classes beyond the chunk's longest read are not launched)
+            uint32_t n_long = 1;
             for (uint32_t i = 0; i < cnt; ++i) {
                 const uint64_t l = boff[first + i + 1] - boff[first + i];
                 const uint64_t nk = l < db->dev.k ? 0 : 2 * (l - db->dev.k + 1);
-                if (nk > cls::MAX_READ_KMERS) { ++n_long; longest = std::max(longest, std::min(l, HARD_MAX_READ_LEN)); }
+                longest = std::max(longest, std::min(l, HARD_MAX_READ_LEN));
+                if (nk > cls::MAX_READ_KMERS) ++n_long;
             }
             rc = place_device(db, dv.d_bases, (const uint64_t*)dv.d_base_off + first, cnt, params, d_out, nullptr, stream, (uint32_t)(2 * longest), n_long);
             if (rc != CLS_OK) { cleanup(); return rc; }

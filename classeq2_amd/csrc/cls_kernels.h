@@ -43,6 +43,7 @@ struct PlacePlan {
     uint64_t long_set;         // entries of the distinct-hit set (power of two)
     uint64_t long_stride_words;
     uint64_t long_off_words;
+    uint32_t max_kmers;        // the longest read the launch is provisioned for: the classes beyond it are not launched
     bool tiled;                // the launch has the LDS-tiled classes (cls_tile.hip)
     bool time_tile;            // ... and its kernel is the one that is timed (a handle provisioned for reads beyond MAX_READ_KMERS, or CLS_TIME_CLASS=2)
     TilePlan tile;
@@ -60,8 +61,9 @@ std::string tile_kernel_name(const DbDev& db, bool stats, uint32_t threads);
 void tile_launch(const DbDev& db, const PlaceParams& prm, const TilePlan& p, bool stats, const uint8_t* d_bases, const uint64_t* d_offsets,
                  const uint32_t* const* sub_lists, const uint32_t* const* sub_lens, uint32_t* big_list, uint32_t* big_len,
                  cls_placement* d_out, cls_query_stats* d_stats, uint32_t* spill_list, uint32_t* spill_len, uint32_t* scratch, hipStream_t stream);
-// `long_cap`: k-mer capacity wanted for reads beyond MAX_READ_KMERS (0 = refuse them), `n_long`: how many
-// such reads the batch may hold (bounds the number of workspace slices).
+// `n_long` != 0: `long_cap` is the k-mer count of the longest read to provision for (classes beyond it are not launched, a
+// longer read may be refused) and `n_long` how many reads beyond the wave-per-read kernels the batch may hold (bounds the grids
+// and the workspace slices); `n_long` == 0: reads of up to MAX_READ_KMERS k-mers.
 PlacePlan plan_place(const DbDev& db, uint32_t n_reads, uint32_t n_cu, bool stats, uint32_t long_cap, uint32_t n_long);
 // Template instance of the class-0 placement kernel launch_place() picks for `db` (as rocprofv3 names it).
 std::string dominant_kernel_name(const DbDev& db, bool stats, const PlacePlan* plan = nullptr);

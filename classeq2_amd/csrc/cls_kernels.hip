@@ -2505,29 +2505,31 @@ PlacePlan plan_place(const DbDev& db, uint32_t n_reads, uint32_t n_cu, bool stat
     p.child_off_words = w;
     w += child_words;
     w += w & 1;
+    // The longest read the launch is provisioned for: the classes beyond it are not launched (a longer read may be refused).
+    p.max_kmers = n_long ? std::max<uint32_t>(long_cap, 2u) : MAX_READ_KMERS;
     // LDS-tiled classes (cls_tile.hip): every read beyond the wave-per-read kernels when the index has the shape for it --
     // the workgroup-per-read kernel then only sees reads of an index that has not (measured on 300-leaf indexes, k = 15 / 35,
     // binary / support-collapsed: 600 bp reads 3.3-4.9 M reads/s there against 23-48 M here, 1.9 kb 2.2-3.5 M against 7.6-17.6 M)
     const uint32_t blk_cap = (uint32_t)(64 * BLK_WAVES * BLK_SLOTS);
     p.tile_from = blk_cap;
-    const uint32_t long_want = n_long ? long_cap : 0u;  // (reads beyond MAX_READ_KMERS: only when the caller provisions for them)
     if (tile_usable(db)) {
         p.tile_from = tuning().tile_min_kmers > 0 ? std::min<uint32_t>(blk_cap, (uint32_t)tuning().tile_min_kmers) : (uint32_t)(64 * CLS_SLOTS[1]);
-        p.tile = tile_plan(db, p.tile_from, std::max<uint32_t>(long_want, MAX_READ_KMERS), n_reads, n_cu);
-        p.tiled = p.tile.whole.cap_kmers > p.tile_from;
+        if (p.max_kmers > p.tile_from) {
+            p.tile = tile_plan(db, p.tile_from, p.max_kmers, n_reads, n_cu);
+            p.tiled = p.tile.whole.cap_kmers > p.tile_from;
+        }
     }
     if (p.tiled) {
-        p.time_tile = long_want > MAX_READ_KMERS || tuning().time_class == 2;
+        p.time_tile = p.max_kmers > MAX_READ_KMERS || tuning().time_class == 2;
         p.tile_name_threads = p.tile.whole.threads;
-        const uint32_t longest = long_want ? long_want : MAX_READ_KMERS;
-        for (uint32_t i = p.tile.n_sub; i-- > 0;) if (p.tile.sub[i].cap_kmers >= longest) p.tile_name_threads = p.tile.sub[i].threads;
+        for (uint32_t i = p.tile.n_sub; i-- > 0;) if (p.tile.sub[i].cap_kmers >= p.max_kmers) p.tile_name_threads = p.tile.sub[i].threads;
         p.tile_off_words = w;
         w += p.tile.scratch_words;
         w += w & 1;
     } else p.tile_from = blk_cap;
     // long-read class: per workgroup two state buffers (the distinct-hit set shares the second) + child counters
-    if ((long_cap > MAX_READ_KMERS && n_long) || p.tiled) {  // (the LDS-tiled kernel spills to this one)
-        long_cap = std::max<uint32_t>(long_want, MAX_READ_KMERS);
+    if (p.max_kmers > MAX_READ_KMERS || p.tiled) {  // (the LDS-tiled kernel spills to this one)
+        long_cap = p.max_kmers;
         p.long_cap = long_cap;
         p.long_set = 1;
         while (p.long_set < 2 * (uint64_t)long_cap) p.long_set <<= 1;
@@ -2557,8 +2559,9 @@ hipError_t launch_place(const DbDev& db, const PlaceParams& prm, const PlacePlan
     if (e != hipSuccess) return e;
     {
         ClassCaps caps{};
-        caps.cap[0] = (uint32_t)(64 * CLS_SLOTS[0]); caps.cap[1] = (uint32_t)(64 * CLS_SLOTS[1]);
-        caps.cap[2] = plan.tiled ? plan.tile_from : (uint32_t)(64 * BLK_WAVES * BLK_SLOTS);
+        caps.cap[0] = (uint32_t)(64 * CLS_SLOTS[0]);
+        if (plan.max_kmers > caps.cap[0]) caps.cap[1] = (uint32_t)(64 * CLS_SLOTS[1]);
+        if (plan.max_kmers > (uint32_t)(64 * CLS_SLOTS[1])) caps.cap[2] = plan.tiled ? plan.tile_from : (uint32_t)(64 * BLK_WAVES * BLK_SLOTS);
         if (plan.tiled) {
             for (uint32_t i = 0; i < plan.tile.n_sub; ++i) caps.cap[3 + i] = plan.tile.sub[i].cap_kmers;
             caps.cap[6] = plan.tile.whole.cap_kmers;
@@ -2668,9 +2671,9 @@ hipError_t launch_place(const DbDev& db, const PlaceParams& prm, const PlacePlan
     else launch_class(std::integral_constant<int, CLS_SLOTS[0]>{}, std::integral_constant<int, CLS_SET_BITS[0]>{}, 0);
     if (ev_stop && !time_tile && !time_blk) (void)hipEventRecord(ev_stop, stream);
     if (hipGetLastError() != hipSuccess) return hipErrorLaunchFailure;
-    launch_class(std::integral_constant<int, CLS_SLOTS[1]>{}, std::integral_constant<int, CLS_SET_BITS[1]>{}, 1);
+    if (plan.max_kmers > (uint32_t)(64 * CLS_SLOTS[0])) launch_class(std::integral_constant<int, CLS_SLOTS[1]>{}, std::integral_constant<int, CLS_SET_BITS[1]>{}, 1);
     if (hipGetLastError() != hipSuccess) return hipErrorLaunchFailure;
-    if (!plan.tiled || plan.tile_from > (uint32_t)(64 * CLS_SLOTS[1])) {   // class 2: one workgroup per read (the generic probe path, whatever the index format)
+    if (plan.max_kmers > (uint32_t)(64 * CLS_SLOTS[1]) && (!plan.tiled || plan.tile_from > (uint32_t)(64 * CLS_SLOTS[1]))) {   // class 2: one workgroup per read (the generic probe path, whatever the index format)
         const dim3 grid(plan.grid_blk), block(64 * BLK_WAVES);
         const uint32_t seq_cap = blk_seq_cap(db);
         const size_t smem = blk_smem(db);

@@ -228,10 +228,13 @@ int cls_place_batch(cls_db* db, const char* bases, const uint64_t* offsets, uint
 int cls_place_batch_device(cls_db* db, const void* d_bases, const void* d_offsets, uint32_t n,
                            const cls_params* params, void* d_out, void* d_stats, void* hip_stream);
 
-/* Longest read (bases) cls_place_batch_device() provisions scratch for (the lengths of a device-resident batch
- * are not known to the host).  Default 0: reads of up to 8192 k-mers (4096 + k - 1 bases) only, longer ones are
- * reported CLS_ERR_READ_TOO_LONG; a caller with longer reads opts in here.  Reads with more than 8192 k-mers keep
- * their per-k-mer state in the workspace: 80 bytes per base and resident workgroup.  At most 2^25. */
+/* Longest read (bases) cls_place_batch_device() provisions for (the lengths of a device-resident batch are not
+ * known to the host).  Default 0: reads of up to 8192 k-mers (4096 + k - 1 bases), every read-length class launched;
+ * longer reads are reported CLS_ERR_READ_TOO_LONG.  With n_bases set, the launch follows it: the read-length classes
+ * beyond n_bases are not launched (a batch of 150 bp reads then costs one placement kernel, not one per class) and a
+ * read longer than n_bases may be reported CLS_ERR_READ_TOO_LONG; a caller with reads beyond 8192 k-mers opts in
+ * here.  Reads the LDS-tiled kernel cannot hold keep their per-k-mer state in the workspace: 80 bytes per base and
+ * resident workgroup.  At most 2^25. */
 int cls_db_set_max_read_len(cls_db* db, uint64_t n_bases);
 
 /* Device time of the DOMINANT placement kernel (the wave-per-read kernel of the

@@ -119,6 +119,26 @@ def test_read_too_long_reported():
     assert len(stats_equal(st2, wst)) == 0 and len(stats_equal(hst, wst)) == 0
 
 
+def test_declared_read_length_drops_the_classes_beyond_it():
+    """cls_db_set_max_read_len(n): the device-buffer entry launches the read-length classes up to n only -- same records
+    for the reads within it, CLS_ERR_READ_TOO_LONG for the one beyond; the host-buffer entry sizes itself by the batch."""
+    s = SynthDb(60, 3000, 11, 4, collapse_prob=0.2)
+    rng = np.random.default_rng(12)
+    parts = [ragged_reads(rng, s, 300, 0, 160), ragged_reads(rng, s, 1, 1000, 1001)]
+    bases = np.concatenate([p[0] for p in parts])
+    offsets = np.concatenate([parts[0][1], parts[1][1][1:] + parts[0][1][-1]])
+    want = op.OraclePort(s.flat).place_batch(bases, offsets, op.make_params(), threads=8)
+    with engine.PlacementDb(s.flat, device=0) as db:
+        for n_bases, refused in ((0, False), (160, True), (290, True), (1000, False)):
+            db.set_max_read_len(n_bases)
+            got, _ = _device_place(db, bases, offsets)
+            assert len(records_equal(got[:-1], want[:-1])) == 0
+            assert (got["status"][-1] == _abi.ERR_READ_TOO_LONG) == refused
+            if not refused:
+                assert len(records_equal(got, want)) == 0
+        assert len(records_equal(db.place_batch(bases, offsets), want)) == 0
+
+
 @pytest.mark.parametrize("k,collapse,drop,deep", [(15, 0.0, 0.0, 0), (12, 0.4, 0.0, 0), (11, 0.3, 0.2, 0), (15, 0.0, 0.0, 1), (20, 0.5, 0.0, 1)])
 def test_long_reads_workspace_kernel(k, collapse, drop, deep):
     """Reads of 4.2..11 kb (BASELINE config 5 has 10 kb reads): more k-mers than the register-resident kernels
