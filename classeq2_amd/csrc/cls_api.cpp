@@ -93,6 +93,7 @@ struct cls_db {
     void* d_postings = nullptr;
     void* d_postings2 = nullptr;
     void* d_bucket_key = nullptr;
+    void* d_mz_bucket = nullptr;
     void* d_direct = nullptr;
     void* d_direct16 = nullptr;
     void* d_sets = nullptr;
@@ -176,6 +177,7 @@ extern "C" void cls_db_destroy(cls_db* db) {
     if (db->d_postings) (void)hipFree(db->d_postings);
     if (db->d_postings2) (void)hipFree(db->d_postings2);
     if (db->d_bucket_key) (void)hipFree(db->d_bucket_key);
+    if (db->d_mz_bucket) (void)hipFree(db->d_mz_bucket);
     if (db->d_direct) (void)hipFree(db->d_direct);
     if (db->d_direct16) (void)hipFree(db->d_direct16);
     if (db->d_sets) (void)hipFree(db->d_sets);
@@ -216,6 +218,7 @@ extern "C" int cls_db_create(const cls_db_desc* d, int device, cls_db** out) {
             (e = up(&db->d_postings, E.postings.data(), E.postings.size() * 4)) != hipSuccess ||
             (!E.postings2.empty() && (e = up(&db->d_postings2, E.postings2.data(), E.postings2.size() * 4)) != hipSuccess) ||
             (e = up(&db->d_bucket_key, E.bucket_key.data(), E.bucket_key.size() * 8)) != hipSuccess ||
+            (!E.mz_bucket.empty() && (e = up(&db->d_mz_bucket, E.mz_bucket.data(), E.mz_bucket.size() * 4)) != hipSuccess) ||
             (!E.direct.empty() && (e = up(&db->d_direct, E.direct.data(), E.direct.size() * 4)) != hipSuccess) ||
             (!E.direct16.empty() && (e = up(&db->d_direct16, E.direct16.data(), E.direct16.size() * 4)) != hipSuccess) ||
             (!E.sets.empty() && (e = up(&db->d_sets, E.sets.data(), E.sets.size() * sizeof(cls::SetRec))) != hipSuccess) ||
@@ -230,6 +233,7 @@ extern "C" int cls_db_create(const cls_db_desc* d, int device, cls_db** out) {
         v.postings = (const uint32_t*)db->d_postings;
         v.postings2 = (const uint32_t*)db->d_postings2;
         v.bucket_key = (const uint64_t*)db->d_bucket_key;
+        v.mz_bucket = (const uint32_t*)db->d_mz_bucket;
         v.direct = (const uint32_t*)db->d_direct;
         v.direct16 = (const uint32_t*)db->d_direct16;
         v.sets = (const cls::SetRec*)db->d_sets;
@@ -258,7 +262,7 @@ extern "C" int cls_db_create(const cls_db_desc* d, int device, cls_db** out) {
         i.n_closed_kmers = E.n_closed;
         i.table_slots = E.table.size();
         i.postings_words = E.postings.size();
-        i.hbm_bytes = E.nodes.size() * sizeof(cls::DNode) + E.table.size() * sizeof(cls::Slot) + (E.postings.size() + E.postings2.size()) * 4 + E.bucket_key.size() * 8 + E.direct.size() * 4 + E.direct16.size() * 4 + (E.sets.size() + E.sets2.size()) * sizeof(cls::SetRec);
+        i.hbm_bytes = E.nodes.size() * sizeof(cls::DNode) + E.table.size() * sizeof(cls::Slot) + (E.postings.size() + E.postings2.size()) * 4 + E.bucket_key.size() * 8 + E.mz_bucket.size() * 4 + E.direct.size() * 4 + E.direct16.size() * 4 + (E.sets.size() + E.sets2.size()) * sizeof(cls::SetRec);
         i.max_read_kmers = db->max_read_len ? (uint32_t)std::max<uint64_t>(320, 2 * db->max_read_len) : cls::MAX_READ_KMERS;
         i.device = device;
         i.format = E.format;

@@ -608,6 +608,22 @@ int encode_db(const cls_db_desc* d, EncodedDb& E, std::string& err) {
     lap("direct table");
     E.bucket_key.assign(d->bucket_key, d->bucket_key + d->n_buckets);
     if (E.bucket_key.empty()) E.bucket_key.push_back(0);
+    {   // bucket index by the 2-bit code of a k-mer's first m characters (cls_device.h, MZ_TABLE_MAX_M)
+        const uint32_t M = (uint32_t)std::min<uint64_t>(d->m_size, d->k_size);
+        std::unordered_map<uint64_t, uint32_t> by_key;
+        bool distinct = true;
+        for (uint64_t b = 0; b < d->n_buckets; ++b) distinct &= by_key.emplace(d->bucket_key[b], (uint32_t)b).second;
+        if (M <= MZ_TABLE_MAX_M && distinct) {
+            static const char LETTER[4] = {'A', 'C', 'T', 'G'};  // code = (ascii >> 1) & 3
+            E.mz_bucket.assign((size_t)1 << (2 * M), MZ_NO_BUCKET);
+            char buf[MZ_TABLE_MAX_M + 1];
+            for (uint32_t code = 0; code < E.mz_bucket.size(); ++code) {
+                for (uint32_t t = 0; t < M; ++t) buf[t] = LETTER[(code >> (2 * t)) & 3];
+                const auto it = by_key.find(M ? murmur3_h1_bytes(buf, M) : 0ull);
+                if (it != by_key.end()) E.mz_bucket[code] = it->second;
+            }
+        }
+    }
     E.k = (uint32_t)d->k_size;
     E.m = (uint32_t)std::min<uint64_t>(d->m_size, UINT32_MAX);
     E.m_eff = (uint32_t)std::min<uint64_t>(d->m_size, d->k_size);

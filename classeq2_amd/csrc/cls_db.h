@@ -46,6 +46,7 @@ struct EncodedDb {
     bool strictly_binary = false;
     bool canonical = false;           // direct table symmetric under reverse complement
     std::vector<uint64_t> bucket_key;
+    std::vector<uint32_t> mz_bucket;  // m_eff <= MZ_TABLE_MAX_M: per 2-bit code of a k-mer's first m characters the bucket keyed by their hash (cls_device.h)
     HugeVec<SetRec> sets;             // FMT_SPLIT: tip sets (entry 0 = "no such k-mer")
     HugeVec<SetRec> sets2;            // the same for the wave-per-read kernels: a set that spans at most 32 rows carries its bits (MASK halves)
     HugeVec<uint32_t> direct;         // 4^k set ids (FMT_SPLIT, k <= DIRECT_MAX_K) or empty

@@ -45,6 +45,12 @@ struct TSlot {
 // its tip count is <= 3 (0), <= 6 (1), <= 9 (2) or larger / no tips at all (3).  The locality keys prefer the
 // k-mers that are specific to a small clade (order_key_kernel).
 constexpr int TIER_SHIFT = 30;
+// The minimizer-bucket filter (kmers_map.rs:295-297) asks whether the bucket of a table hit is keyed by the hash of the
+// query k-mer's first m characters.  Bucket keys are distinct, so that is "bucket index == the index of the bucket keyed by
+// MurmurHash3(first m characters)" -- a function of 2m bits, tabulated at load time (m = 4, the reference's default: 256
+// entries): no second hash per k-mer and no read of the bucket's key in the kernels.  MZ_NO_BUCKET: no bucket has that key.
+constexpr uint32_t MZ_TABLE_MAX_M = 8;
+constexpr uint32_t MZ_NO_BUCKET = 0xFFFFFFFFu;
 constexpr uint32_t SET_ID_MASK = (1u << TIER_SHIFT) - 1;
 static_assert(sizeof(TSlot) == 16, "TSlot");
 constexpr int LOC_BUCKET_BITS = 24;
@@ -133,6 +139,7 @@ struct DbDev {
     const uint32_t* postings;   // FMT_LIST: u32 words; FMT_SPLIT: TipRec split records (16-byte units)
     const uint32_t* postings2;  // FMT_SPLIT: the same records, same numbering, with MASK halves (above), or nullptr (knob no_mask_halves)
     const uint64_t* bucket_key;
+    const uint32_t* mz_bucket;  // 4^m_eff entries, or nullptr (m_eff > MZ_TABLE_MAX_M): the minimizer-bucket filter without hashing, below
     const uint32_t* direct;     // FMT_SPLIT, k <= DIRECT_MAX_K: 4^k set ids, or nullptr
     const uint32_t* direct16;   // k <= FAT_DIRECT_MAX_K: the same table with the set record inside the entry (below), or nullptr
     const SetRec* sets;         // FMT_SPLIT: tip sets

@@ -86,6 +86,16 @@ __device__ __forceinline__ uint64_t murmur3_h1_lds(const uint8_t* p, uint32_t le
     return m.finish(k1, k2, t, len);
 }
 
+// 2-bit code (A0 C1 T2 G3, first character in the low bits) of the first m <= 8 characters at p (upper-case ACGT in LDS, eight
+// readable bytes): the index into DbDev::mz_bucket
+__device__ __forceinline__ uint32_t lds_prefix_code(const uint8_t* p, uint32_t m) {
+    uint64_t x = (lds_u64(p) >> 1) & 0x0303030303030303ull;
+    x = (x | (x >> 6)) & 0x000F000F000F000Full;
+    x = (x | (x >> 12)) & 0x000000FF000000FFull;
+    x = (x | (x >> 24)) & 0xFFFFull;
+    return (uint32_t)x & ((1u << (2 * m)) - 1u);
+}
+
 __device__ __forceinline__ uint32_t mix32(uint32_t x) {
     x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
     return x;

@@ -1065,9 +1065,10 @@ __device__ __forceinline__ bool hash_front(const DbDev& db, const FastCtx& cx, c
         bool hit = false;
         uint64_t mz = 0;
         uint32_t ent = 0, bucket = 0, slot = 0;
+        const uint32_t* __restrict__ mzb = db.mz_bucket;  // the bucket keyed by the hash of a k-mer's first m characters, tabulated (cls_device.h)
         if (j < nk) {
             const uint64_t h = murmur3_h1_lds(kmer_start(j), k);
-            mz = murmur3_h1_lds(kmer_start(j), m_eff);  // the "minimizer": the hash of the first m characters (kmers_map.rs:10-13)
+            if (!mzb) mz = murmur3_h1_lds(kmer_start(j), m_eff);  // the "minimizer": the hash of the first m characters (kmers_map.rs:10-13)
             uint64_t idx = h & db.table_mask;
             const uint4* __restrict__ ft = reinterpret_cast<const uint4*>(db.table);  // TSlot = {hash lo, hash hi, set, bucket | tier << 30}
 #pragma unroll 1
@@ -1087,15 +1088,17 @@ __device__ __forceinline__ bool hash_front(const DbDev& db, const FastCtx& cx, c
         }
         bool ok = false;
         uint64_t bk = 0;
-        if (hit) { bk = db.bucket_key[bucket]; ok = (bk == mz); ib += 8; }
+        if (hit && mzb) { ok = mzb[lds_prefix_code(kmer_start(j), m_eff)] == bucket; ib += 4; }
+        else if (hit) { bk = db.bucket_key[bucket]; ok = (bk == mz); ib += 8; }
         uint64_t pend = __ballot(hit && !ok);
         while (pend) {  // the bucket's key may still be the minimizer of another query k-mer
             const int src = __ffsll((unsigned long long)pend) - 1;
             const uint64_t B = ((uint64_t)__shfl((uint32_t)(bk >> 32), src) << 32) | __shfl((uint32_t)bk, src);
+            const uint32_t Bi = __shfl(bucket, src);
             bool f = false;
 #pragma unroll 1
             for (uint32_t jj = lane; jj < 2 * nf; jj += 64) {  // every k-mer of the read, both strands
-                f |= murmur3_h1_lds(kmer_start(jj), m_eff) == B;
+                f |= mzb ? mzb[lds_prefix_code(kmer_start(jj), m_eff)] == Bi : murmur3_h1_lds(kmer_start(jj), m_eff) == B;
             }
             const bool any = __ballot(f) != 0;
             if ((int)lane == src) ok = any;

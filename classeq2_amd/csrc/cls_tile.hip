@@ -273,19 +273,23 @@ __global__ __launch_bounds__(THREADS, 4) void place_tile_kernel(DbDev db, PlaceP
                 }
 #pragma unroll
                 for (int q = 0; q < RT_LOOK; ++q) if (jb + q * THREADS + tid < n_look) { sl[q] = table[idx[q]]; if (STATS) ib += 16; }
+                const uint32_t* __restrict__ mzb = db.mz_bucket;  // the bucket keyed by the hash of a k-mer's first m characters, tabulated (cls_device.h)
                 uint64_t bk[RT_LOOK];
 #pragma unroll
                 for (int q = 0; q < RT_LOOK; ++q) {
                     while (sl[q].set != 0 && sl[q].hash != h[q]) { idx[q] = (idx[q] + 1) & tmask; sl[q] = table[idx[q]]; if (STATS) ib += 16; }  // (set == 0: an empty slot, the k-mer is not in the index)
                     bk[q] = 0;
-                    if (sl[q].set != 0) { bk[q] = db.bucket_key[sl[q].bucket & (uint32_t)LOC_BUCKET_MASK]; if (STATS) ib += 8; }
+                    if (sl[q].set != 0 && !mzb) { bk[q] = db.bucket_key[sl[q].bucket & (uint32_t)LOC_BUCKET_MASK]; if (STATS) ib += 8; }
                 }
 #pragma unroll
                 for (int q = 0; q < RT_LOOK; ++q) {
                     v[q] = 0;
                     if (sl[q].set == 0) continue;
                     const uint32_t j = jb + q * THREADS + tid;
-                    if (murmur3_h1_lds(seq + (j < nf ? j : L + (j - nf)), db.m_eff) != bk[q]) { sh.overflow = 1; continue; }
+                    const uint8_t* p = seq + (j < nf ? j : L + (j - nf));
+                    const bool own = mzb ? mzb[lds_prefix_code(p, db.m_eff)] == (sl[q].bucket & (uint32_t)LOC_BUCKET_MASK) : murmur3_h1_lds(p, db.m_eff) == bk[q];
+                    if (STATS && mzb) ib += 4;
+                    if (!own) { sh.overflow = 1; continue; }
                     const uint32_t code = (uint32_t)idx[q];
                     uint32_t pos = (uint32_t)(((uint64_t)(code * 2654435761u) * set_words) >> 32);
                     for (uint32_t probes = 0;; ++probes) {
