@@ -374,6 +374,9 @@ __global__ __launch_bounds__(THREADS, 4) void place_tile_kernel(DbDev db, PlaceP
         }
         // ---- the entries come back from the scratch into the LDS the front has left (a read with more of them than this
         // configuration holds goes to the launch that gives a read the whole LDS) ----
+#ifdef RT_EXPERIMENT_FRONT_ONLY
+        { record(CLS_MAX_RESOLUTION, 0, 0, n_groups, 0); continue; }  // (timing experiment: wrong placements)
+#endif
         if (n_groups > cap_entries) {
             if (tid == 0) big_list[atomicAdd(big_len, 1u)] = r;
             continue;
