@@ -8,6 +8,7 @@ import numpy as np
 import torch
 from classeq2_amd import engine
 engine.tuning_from_env()  # CLS_* experiment knobs (the library never reads the environment on its own)
+engine.set_tuning("time_class", 2)  # name the kernel of the gene-length classes, not the wave-per-read one
 from classeq2_amd.synth import SynthDb
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 4000
