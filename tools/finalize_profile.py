@@ -38,6 +38,10 @@ ksec = r["kernel_ms"] * 1e-3
 r["traffic_frac"] = traffic / ksec / 1e9 / 8000.0
 if r.get("needed_bytes_per_launch"):
     r["overfetch"] = traffic / r["needed_bytes_per_launch"]
+if isinstance(r.get("random_line_rate"), dict):
+    g = traffic / 64.0 / ksec / 1e9
+    r["random_line_rate"]["achieved_glines_per_s"] = g
+    r["random_line_rate"]["frac"] = g / r["random_line_rate"]["peak_glines_per_s"]
 json.dump(b, open(os.path.join(prof, f"{tag}_bench_{cfg}.json"), "w"))
 if len(sys.argv) > 2:
     for suffix in (f"pmc_{cfg}.json", f"kernel_stats_{cfg}.csv", f"bench_{cfg}.json"):
