@@ -120,7 +120,7 @@ namespace {
 struct Knob { const char* name; int cls::Tuning::*field; };
 const Knob KNOBS[] = {
     {"no_fast", &cls::Tuning::no_fast}, {"no_order", &cls::Tuning::no_order}, {"force_list", &cls::Tuning::force_list},
-    {"no_mask_halves", &cls::Tuning::no_mask_halves}, {"no_fat_direct", &cls::Tuning::no_fat_direct}, {"no_tile", &cls::Tuning::no_tile}, {"tile_pass_codes", &cls::Tuning::tile_pass_codes}, {"tile_set_words", &cls::Tuning::tile_set_words}, {"time_class", &cls::Tuning::time_class}, {"tile_one_per_cu", &cls::Tuning::tile_one_per_cu}, {"tile_min_kmers", &cls::Tuning::tile_min_kmers}, {"blocks_per_cu", &cls::Tuning::blocks_per_cu}, {"key_blocks_per_cu", &cls::Tuning::key_blocks_per_cu},
+    {"no_mask_halves", &cls::Tuning::no_mask_halves}, {"no_fat_direct", &cls::Tuning::no_fat_direct}, {"no_tile", &cls::Tuning::no_tile}, {"tile_pass_codes", &cls::Tuning::tile_pass_codes}, {"tile_set_words", &cls::Tuning::tile_set_words}, {"time_class", &cls::Tuning::time_class}, {"tile_one_per_cu", &cls::Tuning::tile_one_per_cu}, {"tile_min_kmers", &cls::Tuning::tile_min_kmers}, {"no_tile_order", &cls::Tuning::no_tile_order}, {"tile_deal", &cls::Tuning::tile_deal}, {"blocks_per_cu", &cls::Tuning::blocks_per_cu}, {"key_blocks_per_cu", &cls::Tuning::key_blocks_per_cu},
     {"long_blocks_per_cu", &cls::Tuning::long_blocks_per_cu}, {"order_mode", &cls::Tuning::order_mode},
     {"order_windows", &cls::Tuning::order_windows}, {"order_both_strands", &cls::Tuning::order_both_strands},
     {"order_block_shift", &cls::Tuning::order_block_shift}, {"order_sample_shift", &cls::Tuning::order_sample_shift},

@@ -60,7 +60,7 @@ std::string tile_kernel_name(const DbDev& db, bool stats, uint32_t threads);
 // entries) are appended to `spill_list`
 void tile_launch(const DbDev& db, const PlaceParams& prm, const TilePlan& p, bool stats, const uint8_t* d_bases, const uint64_t* d_offsets,
                  const uint32_t* const* sub_lists, const uint32_t* const* sub_lens, uint32_t* big_list, uint32_t* big_len,
-                 cls_placement* d_out, cls_query_stats* d_stats, uint32_t* spill_list, uint32_t* spill_len, uint32_t* scratch, hipStream_t stream);
+                 cls_placement* d_out, cls_query_stats* d_stats, uint32_t* spill_list, uint32_t* spill_len, uint32_t* scratch, bool ordered, hipStream_t stream);
 // `n_long` != 0: `long_cap` is the k-mer count of the longest read to provision for (classes beyond it are not launched, a
 // longer read may be refused) and `n_long` how many reads beyond the wave-per-read kernels the batch may hold (bounds the grids
 // and the workspace slices); `n_long` == 0: reads of up to MAX_READ_KMERS k-mers.

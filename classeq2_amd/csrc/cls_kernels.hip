@@ -2298,7 +2298,7 @@ constexpr int CLASSIFY_THREADS = 256, CLASSIFY_PER_THREAD = 4;
 // kernel (and the list the LDS-tiled kernel spills to)
 constexpr int N_LISTS = 8;
 struct ClassCaps { uint32_t cap[N_LISTS]; };  // class c takes the reads of up to cap[c] k-mers that no class before it takes (0: not in this launch)
-__global__ __launch_bounds__(CLASSIFY_THREADS) void classify_kernel(const uint64_t* __restrict__ offsets, uint32_t n_reads, uint32_t k, ClassCaps caps,
+__global__ __launch_bounds__(CLASSIFY_THREADS) void classify_kernel(const uint64_t* __restrict__ offsets, const uint32_t* __restrict__ order, uint32_t n_reads, uint32_t k, ClassCaps caps,
                                                                    uint32_t* __restrict__ lists, uint32_t* __restrict__ counts,
                                                                    cls_placement* __restrict__ out, cls_query_stats* __restrict__ stats) {
     // a workgroup bins 1024 reads: positions inside the workgroup from LDS counters, ONE global atomic per class
@@ -2308,13 +2308,15 @@ __global__ __launch_bounds__(CLASSIFY_THREADS) void classify_kernel(const uint64
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t first = blockIdx.x * (CLASSIFY_THREADS * CLASSIFY_PER_THREAD) + threadIdx.x;
     int cls_id[CLASSIFY_PER_THREAD];
-    uint32_t pos[CLASSIFY_PER_THREAD];
+    uint32_t pos[CLASSIFY_PER_THREAD], rd[CLASSIFY_PER_THREAD];
 #pragma unroll
     for (int i = 0; i < CLASSIFY_PER_THREAD; ++i) {
-        const uint32_t r = first + i * CLASSIFY_THREADS;
+        const uint32_t at = first + i * CLASSIFY_THREADS;
+        const uint32_t r = (order && at < n_reads) ? order[at] : at;  // (`order`: the reads in locality order; the class lists then come out in that order too, near enough)
+        rd[i] = r;
         cls_id[i] = -1;
         pos[i] = 0;
-        if (r < n_reads) {
+        if (at < n_reads) {
             const uint64_t L = offsets[r + 1] - offsets[r];
             const uint64_t nk = L < k ? 0 : 2 * (L - k + 1);
             // (class 0 includes L < k: the kernel reports CLS_ERR_TOO_FEW_KMERS)
@@ -2345,7 +2347,7 @@ __global__ __launch_bounds__(CLASSIFY_THREADS) void classify_kernel(const uint64
 #pragma unroll
     for (int i = 0; i < CLASSIFY_PER_THREAD; ++i) {
         const int c = cls_id[i];
-        if (c >= 0) lists[(size_t)c * n_reads + s_base[c] + pos[i]] = first + i * CLASSIFY_THREADS;
+        if (c >= 0) lists[(size_t)c * n_reads + s_base[c] + pos[i]] = rd[i];
     }
 }
 
@@ -2560,7 +2562,13 @@ hipError_t launch_place(const DbDev& db, const PlaceParams& prm, const PlacePlan
     uint32_t* child_ws = (child_ws_stride(db) && !child_in_lds(db)) ? d_ws + plan.child_off_words : nullptr;
     hipError_t e = hipMemsetAsync(counts, 0, 64, stream);
     if (e != hipSuccess) return e;
-    {
+    // CLS_PROFILE_STOP=1|2 truncates the split kernel after the match / state-init phase (timing
+    // breakdowns only: the records it then writes are meaningless)
+    const uint32_t profile_stop = (uint32_t)tuning().profile_stop;
+    const uint32_t ws_stride = child_ws_stride(db);
+    const bool st = d_stats != nullptr;
+    const bool binary = db.max_nonleaf_arity <= 2;
+    auto classify = [&](const uint32_t* order) {
         ClassCaps caps{};
         caps.cap[0] = (uint32_t)(64 * CLS_SLOTS[0]);
         if (plan.max_kmers > caps.cap[0]) caps.cap[1] = (uint32_t)(64 * CLS_SLOTS[1]);
@@ -2571,16 +2579,11 @@ hipError_t launch_place(const DbDev& db, const PlaceParams& prm, const PlacePlan
         }
         caps.cap[7] = plan.long_cap;
         hipLaunchKernelGGL(classify_kernel, dim3((n_reads + CLASSIFY_THREADS * CLASSIFY_PER_THREAD - 1) / (CLASSIFY_THREADS * CLASSIFY_PER_THREAD)), dim3(CLASSIFY_THREADS), 0, stream,
-                           d_offsets, n_reads, db.k, caps, lists[0], counts, d_out, d_stats);
-    }
-    // CLS_PROFILE_STOP=1|2 truncates the split kernel after the match / state-init phase (timing
-    // breakdowns only: the records it then writes are meaningless)
-    const uint32_t profile_stop = (uint32_t)tuning().profile_stop;
-    const uint32_t ws_stride = child_ws_stride(db);
-    const bool st = d_stats != nullptr;
-    const bool binary = db.max_nonleaf_arity <= 2;
+                           d_offsets, order, n_reads, db.k, caps, lists[0], counts, d_out, d_stats);
+    };
     const uint32_t* list0 = lists[0];
     uint32_t list0_n = 0, xcd_chunks = 0;
+    if (!plan.ordered) classify(nullptr);
     if (plan.ordered) {
         uint64_t* keys_in = reinterpret_cast<uint64_t*>(d_ws + plan.keys_off_words);
         uint64_t* keys_out = keys_in + n_reads;
@@ -2595,10 +2598,13 @@ hipError_t launch_place(const DbDev& db, const PlaceParams& prm, const PlacePlan
         const size_t smem_k = (size_t)WAVES_PER_BLOCK * (ac + (db.direct ? 4u * (((ac >> 4) + 2 + 3) & ~3u) : 0u) + 16u);
         // windows of a read that make its key (CLS_ORDER_WINDOWS; 64 = one lookup slot per lane, 160 = all of a 150 bp read)
         const uint32_t key_windows = (uint32_t)tn.order_windows;
+        // the reads that get a key: those of the two wave-per-read classes and, when the launch has them, of the LDS-tiled classes
+        // (by their first windows: reads of one neighbourhood of the tree then share table lines, set records and split halves in L2)
+        const uint32_t key_cap = (plan.tiled && !tn.no_tile_order) ? 0xFFFFFFFFu : (uint32_t)(64 * CLS_SLOTS[1]);
 #define CLS_LAUNCH_KEY_S(SL, A32, FW, HS)                                                                                                 \
     hipLaunchKernelGGL((order_key_kernel<SL, A32, FW, HS>), dim3(plan.grid_key), dim3(64 * WAVES_PER_BLOCK), smem_k, stream, db,          \
                        d_bases, d_offsets, n_reads, keys_in, idx_in, ac, key_mode, block_shift, sample_shift, fwd_only,                    \
-                       (uint32_t)(64 * CLS_SLOTS[1]))
+                       key_cap)
 #define CLS_LAUNCH_KEY(A32, HS)                                                                                                           \
     do {                                                                                                                                  \
         if (fwd_only && key_windows <= 64) CLS_LAUNCH_KEY_S(2, A32, true, HS);                                                            \
@@ -2610,10 +2616,10 @@ hipError_t launch_place(const DbDev& db, const PlaceParams& prm, const PlacePlan
             const uint32_t grid_half = std::max<uint32_t>(1, std::min<uint32_t>((n_reads + 2 * WAVES_PER_BLOCK - 1) / (2 * WAVES_PER_BLOCK), plan.grid_key));
             if (db.addr32)
                 hipLaunchKernelGGL((order_key_half_kernel<true>), dim3(grid_half), dim3(64 * WAVES_PER_BLOCK), 0, stream, db, d_bases, d_offsets,
-                                   n_reads, keys_in, idx_in, key_mode, block_shift, (uint32_t)(64 * CLS_SLOTS[1]));
+                                   n_reads, keys_in, idx_in, key_mode, block_shift, key_cap);
             else
                 hipLaunchKernelGGL((order_key_half_kernel<false>), dim3(grid_half), dim3(64 * WAVES_PER_BLOCK), 0, stream, db, d_bases, d_offsets,
-                                   n_reads, keys_in, idx_in, key_mode, block_shift, (uint32_t)(64 * CLS_SLOTS[1]));
+                                   n_reads, keys_in, idx_in, key_mode, block_shift, key_cap);
         }
         else if (fast_mode(db) == 2) CLS_LAUNCH_KEY(true, true);
         else if (db.addr32) CLS_LAUNCH_KEY(true, false);
@@ -2625,6 +2631,7 @@ hipError_t launch_place(const DbDev& db, const PlaceParams& prm, const PlacePlan
         list0 = idx_out;
         list0_n = n_reads;
         xcd_chunks = 1;
+        classify(idx_out);  // (after the order: the lists of the LDS-tiled classes come out in locality order)
     }
     auto launch_class = [&](auto slots_c, auto bits_c, int c) {
         constexpr int SLOTS = decltype(slots_c)::value, SET_BITS = decltype(bits_c)::value;
@@ -2701,7 +2708,7 @@ hipError_t launch_place(const DbDev& db, const PlaceParams& prm, const PlacePlan
         const uint32_t* sub_lists[TILE_MAX_SUB] = {lists[3], lists[4], lists[5]};
         const uint32_t* sub_lens[TILE_MAX_SUB] = {counts + 3, counts + 4, counts + 5};
         tile_launch(db, prm, plan.tile, st, d_bases, d_offsets, sub_lists, sub_lens, lists[6], counts + 6, d_out, d_stats, lists[7], counts + 7,
-                    d_ws + plan.tile_off_words, stream);
+                    d_ws + plan.tile_off_words, plan.ordered && !tuning().no_tile_order, stream);
         if (ev_stop && time_tile) (void)hipEventRecord(ev_stop, stream);
     }
     if (plan.grid_long) {  // class 7: reads beyond what the LDS holds (and every long read of the other index shapes): state in the workspace

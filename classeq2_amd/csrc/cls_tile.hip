@@ -98,7 +98,7 @@ __global__ __launch_bounds__(THREADS, 4) void place_tile_kernel(DbDev db, PlaceP
                                                              const uint32_t* __restrict__ list_len, cls_placement* __restrict__ out,
                                                              cls_query_stats* __restrict__ stats, uint32_t max_lookups, uint32_t max_bases,
                                                              uint32_t pass_codes, uint32_t set_words, uint32_t* __restrict__ spill_list, uint32_t* __restrict__ spill_len,
-                                                             uint32_t cap_entries, uint32_t* __restrict__ gws, uint32_t* __restrict__ big_list, uint32_t* __restrict__ big_len) {
+                                                             uint32_t cap_entries, uint32_t* __restrict__ gws, uint32_t* __restrict__ big_list, uint32_t* __restrict__ big_len, uint32_t xcd_walk) {
     constexpr bool CANON = FRONT == 1, HASHED = FRONT == 2;
     extern __shared__ __align__(16) uint8_t smem[];
     __shared__ RtSh sh;
@@ -123,7 +123,14 @@ __global__ __launch_bounds__(THREADS, 4) void place_tile_kernel(DbDev db, PlaceP
     const uint32_t* __restrict__ half = db.postings;
     const bool rm = prm.remove_intersection != 0;
     const uint32_t n_list = *list_len;
-    for (uint32_t li = blockIdx.x; li < n_list; li += gridDim.x) {
+    // a list in locality order (launch_place): workgroup b runs on XCD b mod 8; the list is dealt to the XCDs in blocks of `xcd_walk`
+    // consecutive reads, so that the reads in flight on one XCD -- one L2 -- are neighbours in the order while all eight advance
+    // through the list together (an eighth of the list per XCD leaves the XCD with the deepest clades working alone at the end)
+    const bool dealt = xcd_walk != 0 && (gridDim.x & 7u) == 0;
+    const uint32_t q_stride = dealt ? gridDim.x >> 3 : gridDim.x;
+    for (uint32_t q = dealt ? blockIdx.x >> 3 : blockIdx.x;; q += q_stride) {
+        const uint32_t li = dealt ? (q / xcd_walk) * (8u * xcd_walk) + (blockIdx.x & 7u) * xcd_walk + q % xcd_walk : q;
+        if (li >= n_list) { if (!dealt || (q / xcd_walk) * (8u * xcd_walk) >= n_list) break; else continue; }
         __syncthreads();  // the previous read's use of the LDS is over
         const uint32_t r = list[li];
         const uint64_t b0 = offsets[r], L64 = offsets[r + 1] - b0;
@@ -391,8 +398,12 @@ __global__ __launch_bounds__(THREADS, 4) void place_tile_kernel(DbDev db, PlaceP
         }
         __syncthreads();
         // ---- C. descent (place_sequence.rs:279-601) -----------------------------------------------------------------------
-        // Every thread owns the same entries at every level (j = tid, tid + THREADS, ...): what it lists it settles and
-        // counts itself, no barrier between those.  Both children's node records arrive a level ahead (one 64-byte
+        // Every thread owns the same entries at every level (its slots j = tid, tid + THREADS, ...: `my_n` of them): what it
+        // lists it settles and counts itself, no barrier between those.
+        // (Measured and rejected, C5: four entries per trip of the level loop with their LDS reads in flight together and one
+        // "any tip outside" test, and a thread closing the gaps its dead entries leave every 8 / 32 levels -- 4.63 -> 4.78 ms per
+        // 4 000 reads at 0.1 scale, 738 k -> 668 k reads/s at full size: the level's time is its dependent chain (reduce,
+        // barrier, decide, node record), not the pass over the entries.)  Both children's node records arrive a level ahead (one 64-byte
         // scalar load per level).
         snode_pair_t C{};
         if (!POLY || (P.s[7] >> 8) == 2) {
@@ -400,9 +411,11 @@ __global__ __launch_bounds__(THREADS, 4) void place_tile_kernel(DbDev db, PlaceP
             if (STATS && tid == 0) ib += 64;
         }
         // exact share of this thread's settled entries against split a1n: k-mers with a tip before it | at or after it << 16
+        uint32_t my_n = tid < n_groups ? (n_groups - tid + THREADS - 1) / THREADS : 0u;
         auto count = [&](uint32_t a1ns) {
             uint32_t da = 0, db_ = 0;
-            for (uint32_t j = tid; j < n_groups; j += THREADS) {
+            for (uint32_t i = 0; i < my_n; ++i) {
+                const uint32_t j = tid + i * THREADS;
                 const uint2 e = ent[j];
                 const uint32_t w = e.x & 0xFFu;  // (0 for a dead and for a pending entry)
                 da += e.x < a1ns ? w : 0u;
@@ -435,7 +448,8 @@ __global__ __launch_bounds__(THREADS, 4) void place_tile_kernel(DbDev db, PlaceP
                 __syncthreads();
                 if (tid == 0) sh.cnt[((uint32_t)iteration + 2u) % 3u] = 0;  // (the binary levels' rotation goes on through this level)
                 uint32_t u_t = 0;
-                for (uint32_t j = tid; j < n_groups; j += THREADS) {
+                for (uint32_t i = 0; i < my_n; ++i) {
+                    const uint32_t j = tid + i * THREADS;
                     const uint2 e = ent[j];
                     uint32_t v = e.x >> 8, xx = xs[j];
                     const uint32_t vh = e.y >> 8, w = e.x & 0xFFu;
@@ -510,7 +524,8 @@ __global__ __launch_bounds__(THREADS, 4) void place_tile_kernel(DbDev db, PlaceP
                 // entry whose tip IS the child has nothing below it), and count against the split of the child's children
                 const uint32_t c0 = P.s[0], c_end = c0 + P.s[1], a1ns = P.s[6] << 8;
                 uint32_t da = 0, db_ = 0;
-                for (uint32_t j = tid; j < n_groups; j += THREADS) {
+                for (uint32_t i = 0; i < my_n; ++i) {
+                    const uint32_t j = tid + i * THREADS;
                     uint2 e = ent[j];
                     if (e.x == RT_DEAD_LO) continue;
                     uint32_t v = e.x >> 8, vh = e.y >> 8, xx = xs[j];
@@ -564,8 +579,8 @@ __global__ __launch_bounds__(THREADS, 4) void place_tile_kernel(DbDev db, PlaceP
             for (int i = 0; i < 8; ++i) Pn.s[i] = right ? C.s[8 + i] : C.s[i];
             if (Pn.s[3] == 0) {  // no non-LEAF child below the chosen clade (update_introspection_node.rs:45-85): the record's counts
                 uint32_t ca = 0, cb = 0, bo = 0;
-                for (uint32_t j = tid; j < n_groups; j += THREADS) {
-                    const uint2 e = ent[j];
+                for (uint32_t i = 0; i < my_n; ++i) {
+                    const uint2 e = ent[tid + i * THREADS];
                     const uint32_t w = e.x & 0xFFu;
                     const bool ina = e.x < a1s, inb = e.y >= a1s;
                     ca += ina ? w : 0u; cb += inb ? w : 0u; bo += (ina && inb) ? w : 0u;
@@ -614,7 +629,8 @@ __global__ __launch_bounds__(THREADS, 4) void place_tile_kernel(DbDev db, PlaceP
                     da += e.x < a1ns ? w : 0u;
                     db_ += e.y >= a1ns ? w : 0u;
                 };
-                for (uint32_t j = tid; j < n_groups; j += THREADS) {
+                for (uint32_t i = 0; i < my_n; ++i) {
+                    const uint32_t j = tid + i * THREADS;
                     uint2 e = ent[j];
                     fix(e, j);
                     tally(e);
@@ -721,7 +737,7 @@ std::string tile_kernel_name(const DbDev& db, bool stats, uint32_t threads) {
 
 void tile_launch(const DbDev& db, const PlaceParams& prm, const TilePlan& p, bool stats, const uint8_t* d_bases, const uint64_t* d_offsets,
                  const uint32_t* const* sub_lists, const uint32_t* const* sub_lens, uint32_t* big_list, uint32_t* big_len,
-                 cls_placement* d_out, cls_query_stats* d_stats, uint32_t* spill_list, uint32_t* spill_len, uint32_t* scratch, hipStream_t stream) {
+                 cls_placement* d_out, cls_query_stats* d_stats, uint32_t* spill_list, uint32_t* spill_len, uint32_t* scratch, bool ordered, hipStream_t stream) {
     // `over`: where a read with more entries than the launch holds goes -- from a shared launch to the WHOLE one, from that
     // (hashed front only) to the workspace kernel
     auto launch = [&](const TileCfg& c, const uint32_t* lst, const uint32_t* len, uint32_t* over_list, uint32_t* over_len) {
@@ -729,13 +745,14 @@ void tile_launch(const DbDev& db, const PlaceParams& prm, const TilePlan& p, boo
         (void)hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c.smem);
         uint32_t max_lookups = c.lookups, max_bases = c.bases, set_words = c.set_words, cap_entries = c.cap_entries;
         uint32_t* gws = scratch + c.scratch_off;
+        uint32_t xcd_walk = ordered ? (uint32_t)std::max(1, tuning().tile_deal) : 0u;
         // the code set: every code in one pass at load <= 0.5 (knobs: fewer words / codes per pass -- tests)
         if (tuning().tile_set_words > 0) set_words = std::min<uint32_t>(set_words, (uint32_t)tuning().tile_set_words);
         uint32_t pass_codes = std::max<uint32_t>(1u, set_words / 2);
         if (tuning().tile_pass_codes > 0) pass_codes = (uint32_t)tuning().tile_pass_codes;
         void* args[] = {(void*)&db, (void*)&prm, (void*)&d_bases, (void*)&d_offsets, (void*)&lst, (void*)&len, (void*)&d_out, (void*)&d_stats,
                         (void*)&max_lookups, (void*)&max_bases, (void*)&pass_codes, (void*)&set_words, (void*)&spill_list, (void*)&spill_len,
-                        (void*)&cap_entries, (void*)&gws, (void*)&over_list, (void*)&over_len};
+                        (void*)&cap_entries, (void*)&gws, (void*)&over_list, (void*)&over_len, (void*)&xcd_walk};
         (void)hipLaunchKernel(kfn, dim3(c.grid), dim3(c.threads), args, c.smem, stream);
     };
     for (uint32_t i = 0; i < p.n_sub; ++i) launch(p.sub[i], sub_lists[i], sub_lens[i], big_list, big_len);

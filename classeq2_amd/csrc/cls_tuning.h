@@ -16,6 +16,8 @@ struct Tuning {
     int tile_set_words = 0;       // CLS_TILE_SET_WORDS: words of that set (0: two per lookup; a small set with one pass overflows on a
                                   // long read, which then takes the spill path: tests)
     int tile_min_kmers = 0;       // CLS_TILE_MIN_KMERS: reads with more k-mers than this take the LDS-tiled kernel rather than the workgroup-per-read one (0: only reads that one cannot hold)
+    int tile_deal = 64;           // CLS_TILE_DEAL: consecutive reads of the locality order an XCD takes at a time (LDS-tiled classes)
+    int no_tile_order = 0;        // CLS_NO_TILE_ORDER: the LDS-tiled classes' reads in batch order, not in locality order
     int tile_one_per_cu = 0;      // CLS_TILE_ONE_PER_CU: the LDS-tiled kernel as ONE 1024-thread workgroup a CU even where two 512-thread ones fit
     int time_class = 0;           // CLS_TIME_CLASS: 2 = cls_db_kernel_time / cls_db_kernel_name follow the workgroup-per-read kernel (reads of 513..4096 + k - 1 bases)
     int blocks_per_cu = 0;        // CLS_BLOCKS_PER_CU: grid of the wave-per-read kernels (0: what is resident)
