@@ -239,7 +239,8 @@ int cls_db_set_max_read_len(cls_db* db, uint64_t n_bases);
 
 /* Device time of the DOMINANT placement kernel (the wave-per-read kernel of the
  * 320-k-mer class; for a handle provisioned for long reads, cls_db_set_max_read_len,
- * the LDS-tiled long-read kernel), accumulated over every cls_place_batch_device() launch on this
+ * the LDS-tiled kernel -- all of its launches together; the tuning knob time_class = 2 selects it for gene-length
+ * reads too), accumulated over every cls_place_batch_device() launch on this
  * handle since the last reset: HIP events recorded around that kernel on the
  * caller's stream.  Waits for the launches still in flight.  Measurement aid for
  * bench.py's roofline figure; `reset` != 0 clears the accumulators afterwards. */
