@@ -460,8 +460,9 @@ def main():
                 "overfetch": (traffic / need) if traffic and need else None,
                 "kernel": kname, "kernel_ms": kernel_ms, "kernel_launches_timed": int(k_cnt),
                 "kernels_timed": "kernel_ms = the placement kernel named in `kernel` only (HIP events on the launch stream: the "
-                                 "wave-per-read kernel of the <= 320-k-mer class, or the LDS-tiled kernel when the handle is provisioned "
-                                 "for long reads); call_ms = the whole call: locality keys + sort + classify + every class",
+                                 "wave-per-read kernel of the <= 320-k-mer class, or all launches of the LDS-tiled kernel when the handle is "
+                                 "provisioned for reads beyond 8192 k-mers or the config's reads are gene-length, G35); call_ms = the whole "
+                                 "call: locality keys + sort + classify + every class",
                 "call_ms": call_ms,
                 # SURVEY.md 8(d)'s model prices streamed posting lists; > 1 by construction for an index that never streams them
                 "survey_model_bytes": model_bytes, "survey_model_frac": model_bytes / ksec / 1e9 / HBM_PEAK_GBS,
